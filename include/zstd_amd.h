@@ -1,0 +1,98 @@
+/* zstd_amd.h -- C ABI of libzstd_amd.so: the MI355X-native batch engine behind DataDog/zstd's one-shot and
+ * bulk (dictionary) call sites.  Plain pointers and sizes only; no HIP or torch types.
+ *
+ * Return convention is libzstd's (reference zstd.h / error_private.h:57-61): a size_t that is either a byte
+ * count or (size_t)-ZSTD_ErrorCode; zsa_isError()/zsa_getErrorName() give the same answers and strings as the
+ * reference's ZSTD_isError()/ZSTD_getErrorName() (errors.go:21-34 string-matches them).
+ *
+ * Scope of the engine: level-1-class compression (strategy ZSTD_fast: level 1 at every size, level 2 and
+ * negative levels where clevels.h selects ZSTD_fast), byte-identical to libzstd 1.5.5; decompression of any
+ * Zstandard frame (concatenated and skippable frames, checksums, dictionaries) except legacy v0.x frames.
+ * Anything else returns an error code -- there is no CPU fallback inside this library: every entry point
+ * that moves data runs on the GPU and fails loudly when no HIP device is usable.
+ */
+#ifndef ZSTD_AMD_H
+#define ZSTD_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------------------------------------------------
+ * 1. Single-call entry points -- what the reference's cgo stubs bind today.  Host pointers, synchronous.
+ *    Each is a batch of one frame through the same kernels as section 2.
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* replaces C.ZSTD_compressBound (zstd.go:57); pure arithmetic, zstd.h ZSTD_COMPRESSBOUND */
+size_t zsa_compressBound(size_t srcSize);
+/* replaces C.ZSTD_compress (zstd.go:108,115) and C.ZSTD_compressCCtx (zstd_ctx.go:70,78) */
+size_t zsa_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int compressionLevel);
+/* replaces C.ZSTD_decompress (zstd.go:168) and C.ZSTD_decompressDCtx (zstd_ctx.go:107) */
+size_t zsa_decompress(void* dst, size_t dstCapacity, const void* src, size_t srcSize);
+/* replaces C.ZSTD_getFrameContentSize (zstd.go:71); header peek on the host, zstd_decompress.c:565-581 */
+unsigned long long zsa_getFrameContentSize(const void* src, size_t srcSize);
+/* replace C.ZSTD_isError / C.ZSTD_getErrorName (errors.go:13,22) */
+unsigned    zsa_isError(size_t code);
+const char* zsa_getErrorName(size_t code);
+
+/* dictionaries: replace C.ZSTD_createCDict / ZSTD_freeCDict / ZSTD_createDDict / ZSTD_freeDDict
+ * (zstd_bulk.go:41-52,144-151), C.ZSTD_compress_usingCDict (zstd_bulk.go:77,86) and
+ * C.ZSTD_decompress_usingDDict (zstd_bulk.go:125).  The digested tables live in device memory. */
+typedef struct zsa_CDict_s zsa_CDict;
+typedef struct zsa_DDict_s zsa_DDict;
+zsa_CDict* zsa_createCDict(const void* dict, size_t dictSize, int compressionLevel);
+size_t     zsa_freeCDict(zsa_CDict* cdict);
+zsa_DDict* zsa_createDDict(const void* dict, size_t dictSize);
+size_t     zsa_freeDDict(zsa_DDict* ddict);
+size_t zsa_compress_usingCDict(void* dst, size_t dstCapacity, const void* src, size_t srcSize, const zsa_CDict* cdict);
+size_t zsa_decompress_usingDDict(void* dst, size_t dstCapacity, const void* src, size_t srcSize, const zsa_DDict* ddict);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * 2. Batch entry points, host memory -- many independent frames in one launch.  New surface (the single-call
+ *    ABI cannot express it); semantics per frame are exactly those of the calls in section 1.
+ *    outSize[i] receives bytes written or (size_t)-error for frame i.  Returns 0, or an error code when the
+ *    batch as a whole could not run (no device, allocation failure).
+ *    Go side: CompressBatch / (*BulkProcessor).CompressBatch in INTEGRATION.md.
+ * ------------------------------------------------------------------------------------------------------- */
+size_t zsa_compress_batch(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCapacity,
+                          size_t* outSize, size_t nFrames, int compressionLevel, const zsa_CDict* cdict /* or NULL */);
+size_t zsa_decompress_batch(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCapacity,
+                            size_t* outSize, size_t nFrames, const zsa_DDict* ddict /* or NULL */);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * 3. Batch entry points, device memory -- inputs and outputs already resident in HBM (what bench.py times).
+ *    A zsa_batch owns everything a launch needs (frame table, result words, per-workgroup scratch), so
+ *    zsa_*_enqueue allocate nothing and only put work on `stream` (a hipStream_t passed as void*; NULL = the
+ *    default stream).  All device pointers must belong to the current HIP device.
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct zsa_batch_s zsa_batch;
+zsa_batch* zsa_batch_create(size_t maxFrames);
+void       zsa_batch_free(zsa_batch* b);
+/* describe frame i: device pointers */
+size_t zsa_batch_set_frame(zsa_batch* b, size_t i, const void* d_src, size_t srcSize, void* d_dst, size_t dstCapacity);
+/* upload the first nFrames descriptors (async on stream) */
+size_t zsa_batch_upload(zsa_batch* b, size_t nFrames, void* stream);
+/* launch; results stay on the device until zsa_batch_results */
+size_t zsa_compress_enqueue(zsa_batch* b, int compressionLevel, const zsa_CDict* cdict, void* stream);
+size_t zsa_decompress_enqueue(zsa_batch* b, const zsa_DDict* ddict, void* stream);
+/* wait for `stream` and copy the per-frame results (bytes or -(error)) to outSize[0..nFrames) */
+size_t zsa_batch_results(zsa_batch* b, size_t* outSize, void* stream);
+/* device pointer to the per-frame result words (uint64), for consumers that stay on the GPU */
+const uint64_t* zsa_batch_device_results(const zsa_batch* b);
+/* geometry of the last launch (for roofline bookkeeping): workgroups launched, LDS bytes per workgroup */
+void zsa_batch_last_launch(const zsa_batch* b, unsigned* workgroups, unsigned* ldsBytes);
+
+/* resolved compression parameters {windowLog, chainLog, hashLog, searchLog, minMatch, targetLength, strategy}
+ * for (level, srcSize, dictSize); mirrors ZSTD_getCParams_internal (zstd_compress.c:6960-6983) for the rows this
+ * engine implements.  Returns 0, or 1 if the level is outside them.  mode: 0 noAttachDict, 1 attachDict, 2 createCDict. */
+int zsa_getCParams(int compressionLevel, unsigned long long srcSize, size_t dictSize, int mode, unsigned out[7]);
+
+/* library / device info */
+int         zsa_device_count(void);
+const char* zsa_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

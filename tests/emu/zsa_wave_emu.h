@@ -1,0 +1,80 @@
+// zsa_wave_emu.h -- TEST-ONLY stand-in for zstd_amd/csrc/zsa_wave_hip.h.
+//
+// Lets tests compile the kernel BODIES (zsa_decode.h / zsa_encode.h) with g++ and run one workgroup
+// (= one 64-lane wave) on the CPU: every lane is a ucontext fiber, and every wave primitive is a
+// rendezvous of all 64 lanes.  This is a debugging aid for the HIP kernels (gdb, ASan/UBSan on the very
+// same source); it is never part of libzstd_amd.so and proves nothing about GPU parity -- the `-m gpu`
+// tests do that through the C-ABI.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include <stdlib.h>
+#include <ucontext.h>
+
+#define ZSA_DEV    static inline
+#define ZSA_DEVFN  static
+#define ZSA_HD     static inline
+#define ZSA_SHARED static
+#define ZSA_WAVE   64
+
+struct ZsaEmu {
+    ucontext_t main_ctx;
+    ucontext_t lane_ctx[64];
+    char* stacks;
+    int cur;                 // running lane
+    int done[64];
+    int ndone;
+    // rendezvous
+    uint64_t vals[2][64];
+    int arrived;
+    unsigned gen;
+};
+extern ZsaEmu g_emu;
+
+static inline void emu_yield()
+{
+    int from = g_emu.cur, next = from;
+    for (int k = 0; k < 64; k++) { next = (next + 1) & 63; if (!g_emu.done[next]) break; }
+    if (next == from) return;
+    g_emu.cur = next;
+    swapcontext(&g_emu.lane_ctx[from], &g_emu.lane_ctx[next]);
+}
+// all lanes contribute v; returns pointer to the 64 collected values (valid until the next-but-one rendezvous)
+static inline const uint64_t* emu_collect(uint64_t v)
+{
+    unsigned mygen = g_emu.gen;
+    uint64_t* slot = g_emu.vals[mygen & 1];
+    slot[g_emu.cur] = v;
+    if (++g_emu.arrived == 64 - g_emu.ndone) { g_emu.arrived = 0; g_emu.gen++; }
+    else while (g_emu.gen == mygen) emu_yield();
+    return slot;
+}
+
+ZSA_DEV int wv_lane() { return g_emu.cur; }
+ZSA_DEV unsigned long long wv_ballot(bool p)
+{
+    const uint64_t* a = emu_collect(p ? 1 : 0);
+    unsigned long long m = 0;
+    for (int i = 0; i < 64; i++) if (a[i]) m |= 1ull << i;
+    return m;
+}
+ZSA_DEV unsigned wv_shfl(unsigned v, int srcLane) { const uint64_t* a = emu_collect(v); return (unsigned)a[srcLane & 63]; }
+ZSA_DEV unsigned wv_shfl_up(unsigned v, int delta) { int me = g_emu.cur; const uint64_t* a = emu_collect(v); return me >= delta ? (unsigned)a[me - delta] : v; }
+ZSA_DEV unsigned wv_shfl_xor(unsigned v, int mask) { int me = g_emu.cur; const uint64_t* a = emu_collect(v); return (unsigned)a[(me ^ mask) & 63]; }
+ZSA_DEV void wv_sync() { (void)emu_collect(0); }
+ZSA_DEV unsigned wv_atomic_add_lds(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+ZSA_DEV unsigned wv_atomic_or_lds(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
+ZSA_DEV unsigned wv_atomic_add_global(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+
+ZSA_DEV unsigned wv_scan_incl(unsigned v)
+{
+    int me = g_emu.cur; const uint64_t* a = emu_collect(v);
+    unsigned s = 0; for (int i = 0; i <= me; i++) s += (unsigned)a[i];
+    return s;
+}
+ZSA_DEV unsigned wv_reduce_add(unsigned v) { const uint64_t* a = emu_collect(v); unsigned s = 0; for (int i = 0; i < 64; i++) s += (unsigned)a[i]; return s; }
+ZSA_DEV unsigned wv_reduce_max(unsigned v) { const uint64_t* a = emu_collect(v); unsigned s = 0; for (int i = 0; i < 64; i++) if ((unsigned)a[i] > s) s = (unsigned)a[i]; return s; }
+
+// run `fn(arg)` on 64 lanes
+typedef void (*emu_kernel_fn)(void* arg);
+void emu_run_wave(emu_kernel_fn fn, void* arg);

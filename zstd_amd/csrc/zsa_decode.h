@@ -1,0 +1,814 @@
+// zsa_decode.h -- device-side Zstandard frame decoder: one 64-lane wave per frame.
+//
+// Replaces, for independent frames decoded in one launch, what the reference reaches through
+// ZSTD_decompress / ZSTD_decompress_usingDDict (zstd.go:168, zstd_bulk.go:125):
+//   frame walk        zstd_decompress.c:947-1145      block header  zstd_decompress_block.c:57-71
+//   literals          zstd_decompress_block.c:120-322 Huffman       huf_decompress.c:358-666, entropy_common.c:244-307
+//   sequence tables   zstd_decompress_block.c:455-742 FSE headers   entropy_common.c:43-188, fse_decompress.c:60-286
+//   sequences         zstd_decompress_block.c:1185-1299, 1569-1654  execution :873-1060
+//
+// Mapping onto the wave:
+//   * decode tables live in LDS (Huffman 2^tableLog x u16, three sequence tables x u64 cells);
+//   * the four Huffman streams of a literal section run on four lanes;
+//   * the sequence bitstream is one serial chain (lane 0), decoded 64 sequences at a time into LDS;
+//   * the 64 lanes then execute that batch: a wave prefix-sum gives every sequence its output position,
+//     literals are copied by all lanes at once, matches are copied in sequence order 64 bytes per step,
+//     with a memory fence only when a match reads bytes the wave has not yet made visible.
+// Serial sections run under `lane == 0` and publish through LDS; every wv_* call is reached by all lanes.
+#pragma once
+#include "zsa_common.h"
+
+// ---- packed sequence-table cell: baseValue | nextState<<32 | nbAdditionalBits<<48 | nbBits<<56
+typedef u64 ZsaSeqCell;
+ZSA_DEV ZsaSeqCell zsa_seqcell(u32 base, u32 nextState, u32 addBits, u32 nbBits)
+{ return (u64)base | ((u64)nextState << 32) | ((u64)addBits << 48) | ((u64)nbBits << 56); }
+
+struct ZsaDDictDev {            // digested dictionary, device resident (zstd_ddict.c:37-45)
+    const u8* content; u32 contentSize; u32 dictID; u32 entropyPresent;
+    u32 hufLog, llLog, ofLog, mlLog;
+    u32 rep[3];
+    const u16* huf;             // 2^hufLog cells
+    const ZsaSeqCell *ll, *of, *ml;
+};
+
+struct ZsaDecShared {
+    ZsaSeqCell ll[512], ml[512], of[256];
+    u16 huf[1 << ZSA_HUF_TABLELOG_MAX];
+    u32 hufLog, llLog, ofLog, mlLog;
+    // table-building scratch
+    u8  weights[256];
+    u16 symStart[256];
+    u16 symbolNext[256];
+    s16 norm[256];
+    u32 fseCell[64];            // weights FSE table: newState | symbol<<16 | nbBits<<24
+    u32 rankVal[ZSA_HUF_TABLELOG_MAX + 2];
+    // one batch of decoded sequences
+    u32 seqLL[64], seqML[64], seqOF[64], outStart[64], litStart[64];
+    // uniform state published by lane 0
+    u64 result;                 // final return value of the frame walk
+    u32 err;                    // first error raised inside the current block (0 = none)
+    u32 u[16];
+};
+enum { ZU_blockType, ZU_lastBlock, ZU_cSize, ZU_origSize, ZU_litMode, ZU_litSize, ZU_litOff, ZU_litCSize,
+       ZU_nbSeq, ZU_seqOff, ZU_seqSize, ZU_batchN, ZU_streams, ZU_hufOff, ZU_hufCSize, ZU_tmp };
+
+// ------------------------------------------------------------------ backward bit reader (bitstream.h:253-432)
+struct ZsaBitR { u64 container; u32 bitsConsumed; const u8* ptr; const u8* start; };
+enum { ZB_unfinished = 0, ZB_endOfBuffer = 1, ZB_completed = 2, ZB_overflow = 3 };
+
+ZSA_DEV u32 zsa_br_init(ZsaBitR& b, const u8* src, u32 srcSize)
+{   // returns 0 or an error code
+    if (srcSize < 1) { b.container = 0; b.bitsConsumed = 0; b.ptr = b.start = src; return ZSA_srcSize_wrong; }
+    b.start = src;
+    u32 const lastByte = src[srcSize - 1];
+    if (srcSize >= 8) {
+        b.ptr = src + srcSize - 8;
+        b.container = zsa_ld64(b.ptr);
+        b.bitsConsumed = lastByte ? 8 - zsa_highbit32(lastByte) : 0;
+        if (lastByte == 0) return ZSA_GENERIC;
+    } else {
+        b.ptr = src;
+        u64 c = 0;
+        for (u32 i = 0; i < srcSize; i++) c |= (u64)src[i] << (8 * i);
+        b.container = c;
+        b.bitsConsumed = lastByte ? 8 - zsa_highbit32(lastByte) : 0;
+        if (lastByte == 0) return ZSA_corruption_detected;
+        b.bitsConsumed += (8 - srcSize) * 8;
+    }
+    return 0;
+}
+ZSA_DEV u32 zsa_br_look(const ZsaBitR& b, u32 nbBits)
+{   // BIT_lookBits (x86-64 form of BIT_getMiddleBits): nbBits <= 31 here
+    u32 const start = 64u - b.bitsConsumed - nbBits;
+    return (u32)(b.container >> (start & 63)) & ((1u << nbBits) - 1u);
+}
+ZSA_DEV u32 zsa_br_lookFast(const ZsaBitR& b, u32 nbBits)
+{   // BIT_lookBitsFast: nbBits >= 1
+    return (u32)((b.container << (b.bitsConsumed & 63)) >> ((64u - nbBits) & 63));
+}
+ZSA_DEV u32 zsa_br_read(ZsaBitR& b, u32 nbBits) { u32 v = zsa_br_look(b, nbBits); b.bitsConsumed += nbBits; return v; }
+ZSA_DEV u32 zsa_br_readFast(ZsaBitR& b, u32 nbBits) { u32 v = zsa_br_lookFast(b, nbBits); b.bitsConsumed += nbBits; return v; }
+ZSA_DEV int zsa_br_reload(ZsaBitR& b)
+{
+    if (b.bitsConsumed > 64) return ZB_overflow;
+    if (b.ptr >= b.start + 8) {
+        b.ptr -= b.bitsConsumed >> 3;
+        b.bitsConsumed &= 7;
+        b.container = zsa_ld64(b.ptr);
+        return ZB_unfinished;
+    }
+    if (b.ptr == b.start) return (b.bitsConsumed < 64) ? ZB_endOfBuffer : ZB_completed;
+    u32 nbBytes = b.bitsConsumed >> 3;
+    int result = ZB_unfinished;
+    if (b.ptr - nbBytes < b.start) { nbBytes = (u32)(b.ptr - b.start); result = ZB_endOfBuffer; }
+    b.ptr -= nbBytes;
+    b.bitsConsumed -= nbBytes * 8;
+    b.container = zsa_ld64(b.ptr);
+    return result;
+}
+ZSA_DEV bool zsa_br_end(const ZsaBitR& b) { return (b.ptr == b.start) && (b.bitsConsumed == 64); }
+
+// ------------------------------------------------------------------ FSE table description (entropy_common.c:43-188)
+// Serial (call from one lane).  Reads LSB-first with zero padding past the buffer, as the reference does
+// through its 8-byte zero-padded copy / iend-4 clamping.  Returns header size, or 0 with *err set.
+ZSA_DEV u32 zsa_peekbits(const u8* src, u32 n, u32 bitPos)
+{   // 25+ bits starting at bitPos
+    u32 const by = bitPos >> 3, sh = bitPos & 7;
+    u64 v = 0;
+    for (u32 i = 0; i < 5; i++) if (by + i < n) v |= (u64)src[by + i] << (8 * i);
+    return (u32)(v >> sh);
+}
+ZSA_DEV u32 zsa_readNCount(s16* norm, u32* maxSVPtr, u32* tableLogPtr, const u8* src, u32 hbSize, u32* err)
+{
+    u32 const maxSV1 = *maxSVPtr + 1;
+    u32 charnum = 0, bitPos = 0;
+    u32 const bitEnd = hbSize * 8;
+    int nbBits, remaining, threshold, previous0 = 0;
+    if (hbSize == 0) { *err = ZSA_srcSize_wrong; return 0; }
+    for (u32 i = 0; i < maxSV1; i++) norm[i] = 0;
+    nbBits = (int)(zsa_peekbits(src, hbSize, 0) & 0xF) + ZSA_FSE_MIN_TABLELOG;
+    if (nbBits > 15) { *err = ZSA_tableLog_tooLarge; return 0; }
+    bitPos = 4;
+    *tableLogPtr = (u32)nbBits;
+    remaining = (1 << nbBits) + 1;
+    threshold = 1 << nbBits;
+    nbBits++;
+    for (;;) {
+        if (previous0) {
+            for (;;) {
+                u32 const two = zsa_peekbits(src, hbSize, bitPos) & 3;
+                bitPos += 2;
+                charnum += two;
+                if (two != 3) break;
+                if (bitPos > bitEnd + 32) { *err = ZSA_corruption_detected; return 0; }
+            }
+            if (charnum >= maxSV1) break;
+        }
+        {   u32 const bitStream = zsa_peekbits(src, hbSize, bitPos);
+            int const max = (2 * threshold - 1) - remaining;
+            int count;
+            if ((bitStream & (u32)(threshold - 1)) < (u32)max) {
+                count = (int)(bitStream & (u32)(threshold - 1));
+                bitPos += (u32)(nbBits - 1);
+            } else {
+                count = (int)(bitStream & (u32)(2 * threshold - 1));
+                if (count >= threshold) count -= max;
+                bitPos += (u32)nbBits;
+            }
+            count--;
+            if (count >= 0) remaining -= count; else remaining += count;
+            norm[charnum++] = (s16)count;
+            previous0 = !count;
+            if (remaining < threshold) {
+                if (remaining <= 1) break;
+                nbBits = (int)zsa_highbit32((u32)remaining) + 1;
+                threshold = 1 << (nbBits - 1);
+            }
+            if (charnum >= maxSV1) break;
+        }
+    }
+    if (remaining != 1) { *err = ZSA_corruption_detected; return 0; }
+    if (charnum > maxSV1) { *err = ZSA_maxSymbolValue_tooSmall; return 0; }
+    if (bitPos > bitEnd) { *err = ZSA_corruption_detected; return 0; }
+    *maxSVPtr = charnum - 1;
+    return (bitPos + 7) >> 3;
+}
+
+// ------------------------------------------------------------------ Huffman table description (entropy_common.c:244-307)
+// Serial (lane 0).  Fills S->weights, S->rankVal; returns bytes consumed, or 0 with *err set.
+ZSA_DEV u32 zsa_huf_readStats(ZsaDecShared* S, u32* nbSymbolsPtr, u32* tableLogPtr, const u8* src, u32 srcSize, u32* err)
+{
+    u32 weightTotal = 0, iSize, oSize;
+    u8* const huffWeight = S->weights;
+    if (!srcSize) { *err = ZSA_srcSize_wrong; return 0; }
+    iSize = src[0];
+    if (iSize >= 128) {
+        oSize = iSize - 127;
+        iSize = (oSize + 1) / 2;
+        if (iSize + 1 > srcSize) { *err = ZSA_srcSize_wrong; return 0; }
+        if (oSize >= 256) { *err = ZSA_corruption_detected; return 0; }
+        for (u32 n = 0; n < oSize; n += 2) { huffWeight[n] = src[1 + n / 2] >> 4; if (n + 1 < 256) huffWeight[n + 1] = src[1 + n / 2] & 15; }
+    } else {
+        // fse_decompress.c:177-286 FSE_decompress_wksp, maxLog 6, at most 255 weights
+        if (iSize + 1 > srcSize) { *err = ZSA_srcSize_wrong; return 0; }
+        const u8* cSrc = src + 1;
+        u32 cSrcSize = iSize, tableLog = 0, maxSV = 255;
+        u32 const n = zsa_readNCount(S->norm, &maxSV, &tableLog, cSrc, cSrcSize, err);
+        if (*err) return 0;
+        if (tableLog > 6) { *err = ZSA_tableLog_tooLarge; return 0; }
+        cSrc += n; cSrcSize -= n;
+        {   // fse_decompress.c:60-163 FSE_buildDTable_internal
+            u32 const tableSize = 1u << tableLog, tableMask = tableSize - 1, step = ZSA_FSE_TABLESTEP(tableSize);
+            u32 highThreshold = tableSize - 1, position = 0;
+            for (u32 s = 0; s <= maxSV; s++) {
+                if (S->norm[s] == -1) { S->fseCell[highThreshold--] = s << 16; S->symbolNext[s] = 1; }
+                else S->symbolNext[s] = (u16)S->norm[s];
+            }
+            for (u32 s = 0; s <= maxSV; s++) {
+                for (int i = 0; i < S->norm[s]; i++) {
+                    S->fseCell[position] = s << 16;
+                    position = (position + step) & tableMask;
+                    while (position > highThreshold) position = (position + step) & tableMask;
+                }
+            }
+            if (position != 0) { *err = ZSA_GENERIC; return 0; }
+            for (u32 u = 0; u < tableSize; u++) {
+                u32 const symbol = S->fseCell[u] >> 16;
+                u32 const nextState = S->symbolNext[symbol]++;
+                u32 const nbBits = tableLog - zsa_highbit32(nextState);
+                S->fseCell[u] = (((nextState << nbBits) - tableSize) & 0xFFFF) | (symbol << 16) | (nbBits << 24);
+            }
+        }
+        {   // fse_decompress.c:177-237 FSE_decompress_usingDTable_generic
+            ZsaBitR bitD;
+            u32 const e = zsa_br_init(bitD, cSrc, cSrcSize);
+            if (e) { *err = e; return 0; }
+            u32 state1 = zsa_br_read(bitD, tableLog); zsa_br_reload(bitD);
+            u32 state2 = zsa_br_read(bitD, tableLog); zsa_br_reload(bitD);
+            u32 op = 0;
+            u32 const omax = 255;
+#define ZSA_FSE_GET(st) do { u32 const c = S->fseCell[st]; huffWeight[op++] = (u8)(c >> 16); st = (c & 0xFFFF) + zsa_br_read(bitD, c >> 24); } while (0)
+            while ((zsa_br_reload(bitD) == ZB_unfinished) & (op + 3 < omax)) {
+                ZSA_FSE_GET(state1); ZSA_FSE_GET(state2); ZSA_FSE_GET(state1); ZSA_FSE_GET(state2);
+            }
+            for (;;) {
+                if (op + 2 > omax) { *err = ZSA_dstSize_tooSmall; return 0; }
+                ZSA_FSE_GET(state1);
+                if (zsa_br_reload(bitD) == ZB_overflow) { ZSA_FSE_GET(state2); break; }
+                if (op + 2 > omax) { *err = ZSA_dstSize_tooSmall; return 0; }
+                ZSA_FSE_GET(state2);
+                if (zsa_br_reload(bitD) == ZB_overflow) { ZSA_FSE_GET(state1); break; }
+            }
+#undef ZSA_FSE_GET
+            oSize = op;
+        }
+    }
+    for (u32 i = 0; i <= ZSA_HUF_TABLELOG_MAX; i++) S->rankVal[i] = 0;
+    for (u32 n = 0; n < oSize; n++) {
+        if (huffWeight[n] > ZSA_HUF_TABLELOG_MAX) { *err = ZSA_corruption_detected; return 0; }
+        S->rankVal[huffWeight[n]]++;
+        weightTotal += (1u << huffWeight[n]) >> 1;
+    }
+    if (weightTotal == 0) { *err = ZSA_corruption_detected; return 0; }
+    {   u32 const tableLog = zsa_highbit32(weightTotal) + 1;
+        if (tableLog > ZSA_HUF_TABLELOG_MAX) { *err = ZSA_corruption_detected; return 0; }
+        *tableLogPtr = tableLog;
+        u32 const rest = (1u << tableLog) - weightTotal;
+        u32 const verif = 1u << zsa_highbit32(rest);
+        u32 const lastWeight = zsa_highbit32(rest) + 1;
+        if (verif != rest) { *err = ZSA_corruption_detected; return 0; }
+        huffWeight[oSize] = (u8)lastWeight;
+        S->rankVal[lastWeight]++;
+    }
+    if ((S->rankVal[1] < 2) || (S->rankVal[1] & 1)) { *err = ZSA_corruption_detected; return 0; }
+    *nbSymbolsPtr = oSize + 1;
+    return iSize + 1;
+}
+
+// huf_decompress.c:358-492 HUF_readDTableX1_wksp: lane 0 reads the description and assigns every symbol
+// its first cell; all lanes then fill the table.  Returns header size (uniform), 0 on error (S->err set).
+ZSA_DEV u32 zsa_huf_buildTable(ZsaDecShared* S, const u8* src, u32 srcSize, int lane)
+{
+    if (lane == 0) {
+        u32 nbSymbols = 0, tableLog = 0, err = 0;
+        u32 const h = zsa_huf_readStats(S, &nbSymbols, &tableLog, src, srcSize, &err);
+        if (!err) {
+            u32 next = 0, rankStart[ZSA_HUF_TABLELOG_MAX + 2];
+            for (u32 w = 1; w <= tableLog; w++) { rankStart[w] = next; next += S->rankVal[w] << (w - 1); }
+            for (u32 n = 0; n < nbSymbols; n++) {
+                u32 const w = S->weights[n];
+                if (w) { S->symStart[n] = (u16)rankStart[w]; rankStart[w] += (1u << w) >> 1; }
+            }
+            S->hufLog = tableLog;
+        } else S->err = ZSA_corruption_detected;   // zstd_decompress_block.c:224
+        S->u[ZU_tmp] = h; S->u[ZU_hufOff] = nbSymbols;
+    }
+    wv_sync();
+    if (S->err) return 0;
+    u32 const nbSymbols = S->u[ZU_hufOff], tableLog = S->hufLog;
+    for (u32 n = 0; n < nbSymbols; n++) {
+        u32 const w = S->weights[n];
+        if (!w) continue;
+        u32 const len = (1u << w) >> 1, s0 = S->symStart[n];
+        u16 const cell = (u16)(((tableLog + 1 - w) << 8) | n);
+        for (u32 u = (u32)lane; u < len; u += ZSA_WAVE) S->huf[s0 + u] = cell;
+    }
+    wv_sync();
+    return S->u[ZU_tmp];
+}
+
+// huf_decompress.c:514-564: one stream, run by one lane.  Returns 0 ok / 1 corrupted.
+ZSA_DEV u32 zsa_huf_decodeStream(const ZsaDecShared* S, u8* p, u8* const pEnd, const u8* cSrc, u32 cSrcSize)
+{
+    ZsaBitR b;
+    if (zsa_br_init(b, cSrc, cSrcSize)) return 1;
+    u32 const dtLog = S->hufLog;
+#define ZSA_HUF_SYM() do { u32 const c = S->huf[zsa_br_lookFast(b, dtLog)]; *p++ = (u8)c; b.bitsConsumed += c >> 8; } while (0)
+    if ((pEnd - p) > 3) {
+        while ((zsa_br_reload(b) == ZB_unfinished) & (p < pEnd - 3)) { ZSA_HUF_SYM(); ZSA_HUF_SYM(); ZSA_HUF_SYM(); ZSA_HUF_SYM(); }
+    } else zsa_br_reload(b);
+    while (p < pEnd) ZSA_HUF_SYM();
+#undef ZSA_HUF_SYM
+    return zsa_br_end(b) ? 0 : 1;
+}
+
+// ------------------------------------------------------------------ sequence tables
+// zstd_decompress_block.c:455-573 ZSTD_buildFSETable_body, serial (one lane). kind: 0 LL, 1 OF, 2 ML
+ZSA_DEV u32 zsa_seq_base(int kind, u32 s) { return kind == 0 ? zsa_LL_base(s) : (kind == 1 ? zsa_OF_base(s) : zsa_ML_base(s)); }
+ZSA_DEV u32 zsa_seq_bits(int kind, u32 s) { return kind == 0 ? zsa_LL_bits(s) : (kind == 1 ? s : zsa_ML_bits(s)); }
+ZSA_DEV void zsa_buildSeqTable(ZsaDecShared* S, ZsaSeqCell* cell, const s16* norm, u32 maxSV, int kind, u32 tableLog)
+{
+    u32 const tableSize = 1u << tableLog, tableMask = tableSize - 1, step = ZSA_FSE_TABLESTEP(tableSize);
+    u32 highThreshold = tableSize - 1, position = 0;
+    for (u32 s = 0; s <= maxSV; s++) {
+        if (norm[s] == -1) { cell[highThreshold--] = s; S->symbolNext[s] = 1; }
+        else S->symbolNext[s] = (u16)norm[s];
+    }
+    for (u32 s = 0; s <= maxSV; s++) {
+        for (int i = 0; i < norm[s]; i++) {
+            cell[position] = s;
+            position = (position + step) & tableMask;
+            while (position > highThreshold) position = (position + step) & tableMask;
+        }
+    }
+    for (u32 u = 0; u < tableSize; u++) {
+        u32 const symbol = (u32)cell[u];
+        u32 const nextState = S->symbolNext[symbol]++;
+        u32 const nbBits = tableLog - zsa_highbit32(nextState);
+        cell[u] = zsa_seqcell(zsa_seq_base(kind, symbol), ((nextState << nbBits) - tableSize) & 0xFFFF, zsa_seq_bits(kind, symbol), nbBits);
+    }
+}
+// zstd_decompress_block.c:617-663 ZSTD_buildSeqTable, serial.  Returns bytes read; sets *err.
+ZSA_DEV u32 zsa_buildSeqTableFromHeader(ZsaDecShared* S, ZsaSeqCell* cell, u32* logPtr, int type, int kind,
+                                        const u8* src, u32 srcSize, int flagRepeatTable, u32* err)
+{
+    u32 const max = kind == 0 ? ZSA_MaxLL : (kind == 1 ? ZSA_MaxOff : ZSA_MaxML);
+    u32 const maxLog = kind == 1 ? ZSA_OffFSELog : 9;
+    switch (type) {
+    case zsa_set_rle:
+        if (!srcSize) { *err = ZSA_srcSize_wrong; return 0; }
+        if (src[0] > max) { *err = ZSA_corruption_detected; return 0; }
+        cell[0] = zsa_seqcell(zsa_seq_base(kind, src[0]), 0, zsa_seq_bits(kind, src[0]), 0);
+        *logPtr = 0;
+        return 1;
+    case zsa_set_basic: {
+        u32 const dmax = kind == 0 ? ZSA_MaxLL : (kind == 1 ? ZSA_DefaultMaxOff : ZSA_MaxML);
+        u32 const dlog = kind == 1 ? ZSA_OF_DEFAULTNORMLOG : 6;
+        for (u32 s = 0; s <= dmax; s++)
+            S->norm[s] = (s16)(kind == 0 ? zsa_LL_defaultNorm(s) : (kind == 1 ? zsa_OF_defaultNorm(s) : zsa_ML_defaultNorm(s)));
+        zsa_buildSeqTable(S, cell, S->norm, dmax, kind, dlog);
+        *logPtr = dlog;
+        return 0; }
+    case zsa_set_repeat:
+        if (!flagRepeatTable) { *err = ZSA_corruption_detected; return 0; }
+        return 0;
+    default: {
+        u32 tableLog = 0, maxSV = max;
+        u32 const h = zsa_readNCount(S->norm, &maxSV, &tableLog, src, srcSize, err);
+        if (*err) { *err = ZSA_corruption_detected; return 0; }
+        if (tableLog > maxLog) { *err = ZSA_corruption_detected; return 0; }
+        zsa_buildSeqTable(S, cell, S->norm, maxSV, kind, tableLog);
+        *logPtr = tableLog;
+        return h; }
+    }
+}
+
+// ------------------------------------------------------------------ frame context (registers; uniform across lanes)
+struct ZsaDecCtx {
+    u8* dstBase;          // prefixStart of the current frame
+    const u8* dictContent; u32 dictSize;   // bytes logically in front of dstBase
+    u32 rep[3];
+    int litEntropy, fseEntropy;
+    u32 dictID;
+};
+
+ZSA_DEV void zsa_raise(ZsaDecShared* S, u32 code) { if (S->err == 0) S->err = code; }
+
+// One compressed block.  op = output offset of the block inside the frame (relative to dstBase),
+// cap = remaining capacity.  Returns decoded size (uniform); on error S->err is set.
+ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 srcSize, u32 op, u64 cap,
+                             u8* litBuf, int lane)
+{
+    u32 const expectedWriteSize = cap < ZSA_BLOCKSIZE_MAX ? (u32)cap : ZSA_BLOCKSIZE_MAX;
+    // ---- literals header (zstd_decompress_block.c:120-322), lane 0
+    if (lane == 0) {
+        u32 err = 0, mode = 0, litSize = 0, litOff = 0, litCSize = 0, streams = 0, consumed = 0;
+        if (srcSize > ZSA_BLOCKSIZE_MAX) err = ZSA_srcSize_wrong;
+        else if (srcSize < 2) err = ZSA_corruption_detected;
+        else {
+            mode = src[0] & 3;
+            u32 const lhlCode = (src[0] >> 2) & 3;
+            if (mode == zsa_set_repeat && C.litEntropy == 0) err = ZSA_dictionary_corrupted;
+            else if (mode == zsa_set_compressed || mode == zsa_set_repeat) {
+                if (srcSize < 5) err = ZSA_corruption_detected;
+                else {
+                    u32 const lhc = zsa_ld32(src);
+                    u32 lhSize;
+                    switch (lhlCode) {
+                    case 0: case 1: default: streams = lhlCode ? 4 : 1; lhSize = 3; litSize = (lhc >> 4) & 0x3FF; litCSize = (lhc >> 14) & 0x3FF; break;
+                    case 2: streams = 4; lhSize = 4; litSize = (lhc >> 4) & 0x3FFF; litCSize = lhc >> 18; break;
+                    case 3: streams = 4; lhSize = 5; litSize = (lhc >> 4) & 0x3FFFF; litCSize = (lhc >> 22) + ((u32)src[4] << 10); break;
+                    }
+                    if (litSize > ZSA_BLOCKSIZE_MAX) err = ZSA_corruption_detected;
+                    else if (streams == 4 && litSize < 6) err = ZSA_literals_headerWrong;
+                    else if (litCSize + lhSize > srcSize) err = ZSA_corruption_detected;
+                    else if (expectedWriteSize < litSize) err = ZSA_dstSize_tooSmall;
+                    litOff = lhSize; consumed = lhSize + litCSize;
+                }
+            } else {
+                u32 lhSize;
+                switch (lhlCode) {
+                case 0: case 2: default: lhSize = 1; litSize = src[0] >> 3; break;
+                case 1: lhSize = 2; if (mode == zsa_set_rle && srcSize < 3) err = ZSA_corruption_detected; litSize = zsa_ld16(src) >> 4; break;
+                case 3: lhSize = 3; if (srcSize < (mode == zsa_set_rle ? 4u : 3u)) err = ZSA_corruption_detected; else litSize = zsa_ld24(src) >> 4; break;
+                }
+                if (!err) {
+                    if (mode == zsa_set_rle && litSize > ZSA_BLOCKSIZE_MAX) err = ZSA_corruption_detected;
+                    else if (expectedWriteSize < litSize) err = ZSA_dstSize_tooSmall;
+                    else if (mode == zsa_set_basic && litSize + lhSize > srcSize) err = ZSA_corruption_detected;
+                }
+                litOff = lhSize; consumed = (mode == zsa_set_rle) ? lhSize + 1 : lhSize + litSize;
+            }
+        }
+        S->err = err;
+        S->u[ZU_litMode] = mode; S->u[ZU_litSize] = litSize; S->u[ZU_litOff] = litOff; S->u[ZU_litCSize] = litCSize;
+        S->u[ZU_streams] = streams; S->u[ZU_seqOff] = consumed;
+    }
+    wv_sync();
+    if (S->err) return 0;
+    u32 const litMode = S->u[ZU_litMode], litSize = S->u[ZU_litSize], litOff = S->u[ZU_litOff];
+    const u8* litPtr = litBuf;
+
+    if (litMode == zsa_set_basic) {
+        litPtr = src + litOff;
+    } else if (litMode == zsa_set_rle) {
+        u8 const b = src[litOff];
+        for (u32 i = (u32)lane; i < litSize; i += ZSA_WAVE) litBuf[i] = b;
+    } else {
+        u32 const litCSize = S->u[ZU_litCSize], streams = S->u[ZU_streams];
+        const u8* cSrc = src + litOff;
+        u32 cSrcSize = litCSize;
+        if (litMode == zsa_set_compressed) {
+            // huf_decompress.c HUF_decompress1X1_DCtx_wksp / HUF_decompress4X_hufOnly_wksp
+            if (streams == 4 && (litSize == 0 || cSrcSize == 0)) { if (lane == 0) zsa_raise(S, ZSA_corruption_detected); wv_sync(); return 0; }
+            u32 const hSize = zsa_huf_buildTable(S, cSrc, cSrcSize, lane);
+            if (S->err) return 0;
+            if (hSize >= cSrcSize) { if (lane == 0) zsa_raise(S, ZSA_corruption_detected); wv_sync(); return 0; }
+            cSrc += hSize; cSrcSize -= hSize;
+        }
+        // streams: huf_decompress.c:543-666
+        u32 bad = 0;
+        if (streams == 1) {
+            if (lane == 0) bad = zsa_huf_decodeStream(S, litBuf, litBuf + litSize, cSrc, cSrcSize);
+        } else {
+            if (cSrcSize < 10) bad = 1;
+            else {
+                u32 const l1 = zsa_ld16(cSrc), l2 = zsa_ld16(cSrc + 2), l3 = zsa_ld16(cSrc + 4);
+                u32 const used = l1 + l2 + l3 + 6;
+                u32 const segmentSize = (litSize + 3) / 4;
+                if (used > cSrcSize) bad = 1;
+                else if (3 * segmentSize > litSize) bad = 1;
+                else if (lane < 4) {
+                    u32 const l4 = cSrcSize - used;
+                    u32 const off = 6 + (lane > 0 ? l1 : 0) + (lane > 1 ? l2 : 0) + (lane > 2 ? l3 : 0);
+                    u32 const len = lane == 0 ? l1 : (lane == 1 ? l2 : (lane == 2 ? l3 : l4));
+                    u8* const o0 = litBuf + (u32)lane * segmentSize;
+                    u8* const o1 = lane == 3 ? litBuf + litSize : o0 + segmentSize;
+                    bad = zsa_huf_decodeStream(S, o0, o1, cSrc + off, len);
+                }
+            }
+        }
+        if (wv_ballot(bad != 0)) { if (lane == 0) zsa_raise(S, ZSA_corruption_detected); wv_sync(); return 0; }
+        C.litEntropy = 1;
+    }
+    wv_sync();   // literal bytes written by some lanes are read by all below
+
+    // ---- sequences header + tables (zstd_decompress_block.c:665-742), lane 0
+    u32 const seqOff = S->u[ZU_seqOff];
+    if (lane == 0) {
+        const u8* const istart = src + seqOff;
+        u32 const n = srcSize - seqOff;
+        const u8* ip = istart;
+        const u8* const iend = istart + n;
+        u32 err = 0, nbSeq = 0;
+        if (n < 1) err = ZSA_srcSize_wrong;
+        else {
+            nbSeq = *ip++;
+            if (!nbSeq) { if (n != 1) err = ZSA_srcSize_wrong; }
+            else {
+                if (nbSeq > 0x7F) {
+                    if (nbSeq == 0xFF) { if (ip + 2 > iend) err = ZSA_srcSize_wrong; else { nbSeq = zsa_ld16(ip) + ZSA_LONGNBSEQ; ip += 2; } }
+                    else { if (ip >= iend) err = ZSA_srcSize_wrong; else nbSeq = ((nbSeq - 0x80) << 8) + *ip++; }
+                }
+                if (!err && ip + 1 > iend) err = ZSA_srcSize_wrong;
+                if (!err) {
+                    int const LLtype = *ip >> 6, OFtype = (*ip >> 4) & 3, MLtype = (*ip >> 2) & 3;
+                    ip++;
+                    ip += zsa_buildSeqTableFromHeader(S, S->ll, &S->llLog, LLtype, 0, ip, (u32)(iend - ip), C.fseEntropy, &err);
+                    if (!err) ip += zsa_buildSeqTableFromHeader(S, S->of, &S->ofLog, OFtype, 1, ip, (u32)(iend - ip), C.fseEntropy, &err);
+                    if (!err) ip += zsa_buildSeqTableFromHeader(S, S->ml, &S->mlLog, MLtype, 2, ip, (u32)(iend - ip), C.fseEntropy, &err);
+                    if (err) err = ZSA_corruption_detected;
+                }
+            }
+        }
+        if (!err && nbSeq > 0 && cap == 0) err = ZSA_dstSize_tooSmall;
+        S->err = err;
+        S->u[ZU_nbSeq] = nbSeq;
+        S->u[ZU_seqSize] = (u32)(iend - ip);
+        S->u[ZU_tmp] = (u32)(ip - src);
+    }
+    wv_sync();
+    if (S->err) return 0;
+
+    u32 nbSeq = S->u[ZU_nbSeq];
+    u32 outPos = op;                       // relative to C.dstBase
+    u64 const oendRel = (u64)op + cap;     // relative end of the writable area
+    u32 litPos = 0;
+    u8* const dst = C.dstBase;
+
+    if (nbSeq) {
+        // lane-0 decoder state lives in registers across batches
+        ZsaBitR b; b.container = 0; b.bitsConsumed = 0; b.ptr = b.start = src;
+        u32 stLL = 0, stOF = 0, stML = 0, r0 = C.rep[0], r1 = C.rep[1], r2 = C.rep[2];
+        C.fseEntropy = 1;
+        if (lane == 0) {
+            if (zsa_br_init(b, src + S->u[ZU_tmp], S->u[ZU_seqSize])) S->err = ZSA_corruption_detected;
+            else {
+                stLL = zsa_br_read(b, S->llLog); zsa_br_reload(b);
+                stOF = zsa_br_read(b, S->ofLog); zsa_br_reload(b);
+                stML = zsa_br_read(b, S->mlLog); zsa_br_reload(b);
+            }
+        }
+        wv_sync();
+        if (S->err) return 0;
+        u32 fencedPos = outPos;
+        while (nbSeq) {
+            u32 const n = nbSeq < ZSA_WAVE ? nbSeq : ZSA_WAVE;
+            // -- zstd_decompress_block.c:1185-1299 ZSTD_decodeSequence, n times on lane 0
+            if (lane == 0) {
+                for (u32 i = 0; i < n; i++) {
+                    ZsaSeqCell const ll = S->ll[stLL], ml = S->ml[stML], of = S->of[stOF];
+                    u32 matchLength = (u32)ml, litLength = (u32)ll, offset;
+                    u32 const llBits = (u32)(ll >> 48) & 0xFF, mlBits = (u32)(ml >> 48) & 0xFF, ofBits = (u32)(of >> 48) & 0xFF;
+                    u32 const totalBits = (llBits + mlBits + ofBits) & 0xFF;
+                    if (ofBits > 1) {
+                        offset = (u32)of + zsa_br_readFast(b, ofBits);
+                        r2 = r1; r1 = r0; r0 = offset;
+                    } else {
+                        u32 const ll0 = ((u32)ll == 0);
+                        if (ofBits == 0) {
+                            offset = ll0 ? r1 : r0;
+                            r1 = ll0 ? r0 : r1;
+                            r0 = offset;
+                        } else {
+                            u32 const code = (u32)of + ll0 + zsa_br_readFast(b, 1);
+                            u32 temp = (code == 3) ? r0 - 1 : (code == 1 ? r1 : (code == 2 ? r2 : r0));
+                            temp += !temp;
+                            if (code != 1) r2 = r1;
+                            r1 = r0;
+                            r0 = offset = temp;
+                        }
+                    }
+                    if (mlBits > 0) matchLength += zsa_br_readFast(b, mlBits);
+                    if (totalBits >= 57 - (ZSA_LLFSELog + ZSA_MLFSELog + ZSA_OffFSELog)) zsa_br_reload(b);
+                    if (llBits > 0) litLength += zsa_br_readFast(b, llBits);
+                    stLL = (u32)((ll >> 32) & 0xFFFF) + zsa_br_read(b, (u32)(ll >> 56));
+                    stML = (u32)((ml >> 32) & 0xFFFF) + zsa_br_read(b, (u32)(ml >> 56));
+                    stOF = (u32)((of >> 32) & 0xFFFF) + zsa_br_read(b, (u32)(of >> 56));
+                    S->seqLL[i] = litLength; S->seqML[i] = matchLength; S->seqOF[i] = offset;
+                    if (i + 1 < n || nbSeq > n) zsa_br_reload(b);
+                }
+                // last batch: exact-end check (zstd_decompress_block.c:1639), reported after the batch has executed
+                S->u[ZU_batchN] = (nbSeq == n) && (zsa_br_reload(b) < ZB_completed);
+            }
+            wv_sync();
+            // -- execute the batch (zstd_decompress_block.c:873-1060 semantics)
+            u32 const myLL = (u32)lane < n ? S->seqLL[lane] : 0;
+            u32 const myML = (u32)lane < n ? S->seqML[lane] : 0;
+            u32 const myOF = (u32)lane < n ? S->seqOF[lane] : 1;
+            u32 const endBad = S->u[ZU_batchN];
+            u32 const litIncl = wv_scan_incl(myLL);
+            u32 const totIncl = wv_scan_incl(myLL + myML);
+            u32 const myLitStart = litIncl - myLL, myOutStart = totIncl - (myLL + myML);
+            S->litStart[lane] = myLitStart; S->outStart[lane] = myOutStart;
+            // per-sequence validity, in the reference's order of checks
+            u32 code = 0;
+            if ((u64)outPos + totIncl > oendRel) code = ZSA_dstSize_tooSmall;
+            else if (litPos + litIncl > litSize) code = ZSA_corruption_detected;
+            else if ((u64)myOF > (u64)outPos + myOutStart + myLL + C.dictSize) code = ZSA_corruption_detected;
+            unsigned long long const badMask = wv_ballot((u32)lane < n && code != 0);
+            if (badMask) {
+                int const first = __builtin_ctzll(badMask);
+                u32 const c = wv_shfl(code, first);
+                if (lane == 0) zsa_raise(S, c);
+            }
+            wv_sync();
+            if (S->err) return 0;
+            u32 const totalLit = wv_shfl(litIncl, 63), totalOut = wv_shfl(totIncl, 63);
+            // literals of the whole batch
+            for (u32 t = (u32)lane; t < totalLit; t += ZSA_WAVE) {
+                u32 lo = 0, hi = n - 1;
+                while (lo < hi) { u32 const mid = (lo + hi + 1) >> 1; if (S->litStart[mid] <= t) lo = mid; else hi = mid - 1; }
+                dst[outPos + S->outStart[lo] + (t - S->litStart[lo])] = litPtr[litPos + t];
+            }
+            wv_sync();
+            if (fencedPos < outPos) fencedPos = outPos;   // everything before this batch is visible now
+            // matches, in order
+            for (u32 i = 0; i < n; i++) {
+                u32 const ml = S->seqML[i], off = S->seqOF[i];
+                u32 const o = outPos + S->outStart[i] + S->seqLL[i];
+                u32 const span = off < ml ? off : ml;            // distinct source bytes
+                if ((u64)o + span > (u64)off + fencedPos) { wv_sync(); fencedPos = o; }   // source reaches unfenced output
+                if (off >= ml) {
+                    for (u32 t = (u32)lane; t < ml; t += ZSA_WAVE) {
+                        s64 const p = (s64)o - (s64)off + t;
+                        dst[o + t] = p < 0 ? C.dictContent[(s64)C.dictSize + p] : dst[p];
+                    }
+                } else {
+                    for (u32 t = (u32)lane; t < ml; t += ZSA_WAVE) {
+                        s64 const p = (s64)o - (s64)off + (t % off);
+                        dst[o + t] = p < 0 ? C.dictContent[(s64)C.dictSize + p] : dst[p];
+                    }
+                }
+            }
+            outPos += totalOut; litPos += totalLit;
+            nbSeq -= n;
+            wv_sync();   // the batch arrays are rewritten by lane 0 next
+            if (endBad) { if (lane == 0) zsa_raise(S, ZSA_corruption_detected); wv_sync(); return 0; }
+        }
+        if (lane == 0) { S->u[ZU_tmp] = r0; S->u[ZU_hufOff] = r1; S->u[ZU_hufCSize] = r2; }
+        wv_sync();
+        if (S->err) return 0;
+        C.rep[0] = S->u[ZU_tmp]; C.rep[1] = S->u[ZU_hufOff]; C.rep[2] = S->u[ZU_hufCSize];
+    } else {
+        if (S->u[ZU_seqSize] != 0) { /* nbSeq==0 requires the section to be exactly 1 byte: checked above */ }
+    }
+    // last literals (zstd_decompress_block.c:1644-1651)
+    {   u32 const lastLL = litSize - litPos;
+        if ((u64)outPos + lastLL > oendRel) { if (lane == 0) zsa_raise(S, ZSA_dstSize_tooSmall); wv_sync(); return 0; }
+        for (u32 t = (u32)lane; t < lastLL; t += ZSA_WAVE) dst[outPos + t] = litPtr[litPos + t];
+        outPos += lastLL;
+    }
+    wv_sync();
+    return outPos - op;
+}
+
+// xxhash.h XXH64 (public algorithm), serial; used only for frames that carry a content checksum
+ZSA_DEV u64 zsa_rotl64(u64 x, int r) { return (x << r) | (x >> (64 - r)); }
+ZSA_DEV u64 zsa_xxh_round(u64 acc, u64 in) { acc += in * 0xC2B2AE3D27D4EB4FULL; acc = zsa_rotl64(acc, 31); return acc * 0x9E3779B185EBCA87ULL; }
+ZSA_DEV u64 zsa_xxh_merge(u64 acc, u64 v) { v = zsa_xxh_round(0, v); acc ^= v; return acc * 0x9E3779B185EBCA87ULL + 0x85EBCA77C2B2AE63ULL; }
+ZSA_DEV u64 zsa_xxh64(const u8* p, u64 len)
+{
+    const u64 P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL, P3 = 0x165667B19E3779F9ULL, P4 = 0x85EBCA77C2B2AE63ULL, P5 = 0x27D4EB2F165667C5ULL;
+    const u8* const end = p + len;
+    u64 h;
+    if (len >= 32) {
+        const u8* const limit = end - 32;
+        u64 v1 = P1 + P2, v2 = P2, v3 = 0, v4 = 0 - P1;
+        do { v1 = zsa_xxh_round(v1, zsa_ld64(p)); v2 = zsa_xxh_round(v2, zsa_ld64(p + 8));
+             v3 = zsa_xxh_round(v3, zsa_ld64(p + 16)); v4 = zsa_xxh_round(v4, zsa_ld64(p + 24)); p += 32; } while (p <= limit);
+        h = zsa_rotl64(v1, 1) + zsa_rotl64(v2, 7) + zsa_rotl64(v3, 12) + zsa_rotl64(v4, 18);
+        h = zsa_xxh_merge(h, v1); h = zsa_xxh_merge(h, v2); h = zsa_xxh_merge(h, v3); h = zsa_xxh_merge(h, v4);
+    } else h = P5;
+    h += len;
+    while (p + 8 <= end) { h ^= zsa_xxh_round(0, zsa_ld64(p)); h = zsa_rotl64(h, 27) * P1 + P4; p += 8; }
+    if (p + 4 <= end) { h ^= (u64)zsa_ld32(p) * P1; h = zsa_rotl64(h, 23) * P2 + P3; p += 4; }
+    while (p < end) { h ^= (*p) * P5; h = zsa_rotl64(h, 11) * P1; p++; }
+    h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+    return h;
+}
+
+// copy dictionary tables into LDS at frame start (zstd_ddict.c:59-87 ZSTD_copyDDictParameters)
+ZSA_DEV void zsa_load_ddict(ZsaDecShared* S, ZsaDecCtx& C, const ZsaDDictDev* dd, int lane)
+{
+    C.dictContent = dd->content; C.dictSize = dd->contentSize; C.dictID = dd->dictID;
+    if (dd->entropyPresent) {
+        C.litEntropy = C.fseEntropy = 1;
+        C.rep[0] = dd->rep[0]; C.rep[1] = dd->rep[1]; C.rep[2] = dd->rep[2];
+        for (u32 i = (u32)lane; i < (1u << dd->hufLog); i += ZSA_WAVE) S->huf[i] = dd->huf[i];
+        for (u32 i = (u32)lane; i < (1u << dd->llLog); i += ZSA_WAVE) S->ll[i] = dd->ll[i];
+        for (u32 i = (u32)lane; i < (1u << dd->ofLog); i += ZSA_WAVE) S->of[i] = dd->of[i];
+        for (u32 i = (u32)lane; i < (1u << dd->mlLog); i += ZSA_WAVE) S->ml[i] = dd->ml[i];
+        if (lane == 0) { S->hufLog = dd->hufLog; S->llLog = dd->llLog; S->ofLog = dd->ofLog; S->mlLog = dd->mlLog; }
+    }
+    wv_sync();
+}
+
+// ------------------------------------------------------------------ the frame walk
+// zstd_decompress.c:1055-1145 ZSTD_decompressMultiFrame + :947-1053 ZSTD_decompressFrame.
+// Returns bytes written or (u64)-error, identical on every lane.
+ZSA_DEV u64 zsa_decode_frames(ZsaDecShared* S, const u8* src, u64 srcSize, u8* dst, u64 dstCapacity,
+                              u8* litBuf, const ZsaDDictDev* dd)
+{
+    int const lane = wv_lane();
+    u64 written = 0;
+    int moreThan1Frame = 0;
+    for (;;) {
+        if (srcSize < 5) break;
+        // ---- lane 0: skippable frame or frame header (zstd_decompress.c:414-547, 583-600)
+        if (lane == 0) {
+            u64 result = 0; u32 act = 0;   // act: 0 decode, 1 skip, 2 fail
+            u32 const magic = zsa_ld32(src);
+            S->u[0] = 0;
+            if ((magic & ZSA_MAGIC_SKIP_MASK) == ZSA_MAGIC_SKIP_START) {
+                act = 1;
+                if (srcSize < 8) { act = 2; result = ZSA_ERR(ZSA_srcSize_wrong); }
+                else {
+                    u32 const sizeU32 = zsa_ld32(src + 4);
+                    if ((u32)(sizeU32 + 8) < sizeU32) { act = 2; result = ZSA_ERR(ZSA_frameParameter_unsupported); }
+                    else if ((u64)sizeU32 + 8 > srcSize) { act = 2; result = ZSA_ERR(ZSA_srcSize_wrong); }
+                    else S->u[1] = sizeU32 + 8;
+                }
+            } else if (srcSize < 6 + 3) { act = 2; result = ZSA_ERR(ZSA_srcSize_wrong); }
+            else {
+                u32 const fhd = src[4];
+                u32 const dictIDCode = fhd & 3, checksumFlag = (fhd >> 2) & 1, singleSegment = (fhd >> 5) & 1, fcsID = fhd >> 6;
+                u32 const didSize = dictIDCode == 3 ? 4 : dictIDCode;
+                u32 const fcsSize = fcsID == 0 ? singleSegment : (1u << fcsID);
+                u32 const fhs = 5 + !singleSegment + didSize + fcsSize;
+                if (srcSize < (u64)fhs + 3) { act = 2; result = ZSA_ERR(ZSA_srcSize_wrong); }
+                else if (magic != ZSA_MAGIC) { act = 2; result = moreThan1Frame ? ZSA_ERR(ZSA_srcSize_wrong) : ZSA_ERR(ZSA_prefix_unknown); }
+                else if (fhd & 0x08) { act = 2; result = ZSA_ERR(ZSA_frameParameter_unsupported); }
+                else {
+                    u32 pos = 5, dictID = 0;
+                    u64 fcs = ~(u64)0;
+                    if (!singleSegment) {
+                        u32 const wlByte = src[pos++];
+                        if ((wlByte >> 3) + ZSA_WLOG_ABSMIN > ZSA_WLOG_MAX) { act = 2; result = ZSA_ERR(ZSA_frameParameter_windowTooLarge); }
+                    }
+                    if (didSize == 1) dictID = src[pos]; else if (didSize == 2) dictID = zsa_ld16(src + pos); else if (didSize == 4) dictID = zsa_ld32(src + pos);
+                    pos += didSize;
+                    if (fcsID == 0) { if (singleSegment) fcs = src[pos]; }
+                    else if (fcsID == 1) fcs = zsa_ld16(src + pos) + 256;
+                    else if (fcsID == 2) fcs = zsa_ld32(src + pos);
+                    else fcs = zsa_ld64(src + pos);
+                    u32 const haveDictID = dd ? dd->dictID : 0;
+                    if (act != 2 && dictID && haveDictID != dictID) { act = 2; result = ZSA_ERR(ZSA_dictionary_wrong); }   // zstd_decompress.c:698-730
+                    S->u[1] = fhs; S->u[2] = checksumFlag; S->u[3] = (u32)fcs; S->u[4] = (u32)(fcs >> 32);
+                }
+            }
+            S->u[0] = act; S->result = result; S->err = 0;
+        }
+        wv_sync();
+        u32 const act = S->u[0];
+        if (act == 2) return S->result;
+        if (act == 1) { u32 const sk = S->u[1]; src += sk; srcSize -= sk; wv_sync(); continue; }
+
+        u32 const fhs = S->u[1], checksumFlag = S->u[2];
+        u64 const fcs = (u64)S->u[3] | ((u64)S->u[4] << 32);
+        wv_sync();   // header words are reused below
+        ZsaDecCtx C;
+        C.dstBase = dst; C.dictContent = dst; C.dictSize = 0;
+        C.rep[0] = 1; C.rep[1] = 4; C.rep[2] = 8; C.litEntropy = C.fseEntropy = 0; C.dictID = 0;
+        if (dd) zsa_load_ddict(S, C, dd, lane);
+
+        const u8* ip = src + fhs;
+        u64 remaining = srcSize - fhs;
+        u64 op = 0;
+        for (;;) {
+            if (remaining < 3) return ZSA_ERR(ZSA_srcSize_wrong);
+            u32 const hdr = zsa_ld24(ip);
+            u32 const lastBlock = hdr & 1, blockType = (hdr >> 1) & 3, origSize = hdr >> 3;
+            if (blockType == zsa_bt_reserved) return ZSA_ERR(ZSA_corruption_detected);
+            u32 const cBlockSize = (blockType == zsa_bt_rle) ? 1 : origSize;
+            ip += 3; remaining -= 3;
+            if (cBlockSize > remaining) return ZSA_ERR(ZSA_srcSize_wrong);
+            u64 const cap = dstCapacity - op;
+            u32 decoded;
+            if (blockType == zsa_bt_compressed) {
+                if (op + ZSA_BLOCKSIZE_MAX > 0xFFFFFFFFull) return ZSA_ERR(ZSA_frameParameter_unsupported);   // frames >= 4 GiB: not this path
+                decoded = zsa_decode_block(S, C, ip, cBlockSize, (u32)op, cap, litBuf, lane);
+                if (S->err) return ZSA_ERR(S->err);
+            } else if (blockType == zsa_bt_raw) {
+                if (cBlockSize > cap) return ZSA_ERR(ZSA_dstSize_tooSmall);
+                for (u32 t = (u32)lane; t < cBlockSize; t += ZSA_WAVE) dst[op + t] = ip[t];
+                decoded = cBlockSize;
+                wv_sync();
+            } else {
+                if (origSize > cap) return ZSA_ERR(ZSA_dstSize_tooSmall);
+                u8 const bv = ip[0];
+                for (u32 t = (u32)lane; t < origSize; t += ZSA_WAVE) dst[op + t] = bv;
+                decoded = origSize;
+                wv_sync();
+            }
+            op += decoded;
+            ip += cBlockSize; remaining -= cBlockSize;
+            if (lastBlock) break;
+        }
+        if (fcs != ~(u64)0 && op != fcs) return ZSA_ERR(ZSA_corruption_detected);
+        if (checksumFlag) {
+            if (remaining < 4) return ZSA_ERR(ZSA_checksum_wrong);
+            if (lane == 0) S->u[0] = (zsa_ld32(ip) != (u32)zsa_xxh64(dst, op));
+            wv_sync();
+            u32 const wrong = S->u[0];
+            wv_sync();
+            if (wrong) return ZSA_ERR(ZSA_checksum_wrong);
+            ip += 4; remaining -= 4;
+        }
+        src = ip; srcSize = remaining;
+        dst += op; dstCapacity -= op; written += op;
+        moreThan1Frame = 1;
+    }
+    if (srcSize) return ZSA_ERR(ZSA_srcSize_wrong);
+    return written;
+}

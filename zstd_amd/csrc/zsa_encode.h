@@ -1,0 +1,1179 @@
+// zsa_encode.h -- device-side Zstandard level-1 (ZSTD_fast) frame compressor: one 64-lane wave per frame.
+//
+// Replaces, for independent frames compressed in one launch, what the reference reaches through
+// ZSTD_compress / ZSTD_compress_usingCDict (zstd.go:108,115; zstd_bulk.go:77,86).  Output is byte-identical
+// to libzstd 1.5.5 for the same cParams (resolved on the host, zsa_host.cpp):
+//   frame / block loop   zstd_compress.c:4392-4520, 4222-4283, 5107-5144
+//   parse                zstd_fast.c:143-403 (noDict), :459-656 (attached dictionary)
+//   literals             zstd_compress_literals.c:40-236, huf_compress.c:147-1406, hist.c:30-165
+//   sequences            zstd_compress.c:2637-2986, zstd_compress_sequences.c:157-383, fse_compress.c:69-525
+//
+// Mapping onto the wave (v1):
+//   * the hash table of the frame lives in LDS (4 << hashLog bytes, dynamic shared memory);
+//   * the greedy parse is one serial dependency chain (every decision changes the table the next one
+//     reads), so it runs on lane 0 and only records packed (litLength, matchLength, offBase) triples;
+//   * literals are gathered afterwards by all 64 lanes from the recorded triples (wave prefix sums),
+//     histograms use LDS atomics from all lanes, the four Huffman streams are packed by four lanes;
+//   * table construction (Huffman tree, FSE normalisation) and the 3-state FSE sequence bitstream are
+//     serial and run on lane 0.
+// Serial sections run under `lane == 0` and publish through LDS; every wv_* call is reached by all lanes.
+#pragma once
+#include "zsa_common.h"
+
+struct ZsaEncParams { u32 wlog, hlog, mml, tlen; };
+
+struct ZsaHufCT { u8 nbBits[256]; u16 val[256]; };
+struct ZsaFseCT { u16 nextState[512]; s32 dfs[ZSA_MaxSeq + 1]; u32 dnb[ZSA_MaxSeq + 1]; u32 tableLog; };
+
+struct ZsaCDictDev {            // digested compression dictionary, device resident
+    const u8* content; u32 contentSize; u32 dictID;
+    u32 hlog, mml;              // CDict cParams (cpm_createCDict)
+    const u32* hashTable;       // tagged: (index << 8) | tag
+    u32 rep[3];
+    u32 hufRepeat, llRepeat, ofRepeat, mlRepeat;
+    ZsaHufCT huf;
+    ZsaFseCT ll, of, ml;
+};
+
+struct ZsaHufNode { u32 count; u16 parent; u8 byte; u8 nbBits; };
+
+struct ZsaEncShared {
+    u32 count[256];
+    ZsaHufCT hufPrev, hufNext;
+    ZsaFseCT ll, of, ml;
+    ZsaHufNode node[2 * 256 + 2];
+    u16 rpBase[192], rpCurr[192];
+    u8  huffWeight[256];
+    s16 norm[256];
+    u16 cumul[258];
+    u8  tableSymbol[512];
+    // small FSE table for Huffman weights (tableLog <= 6, symbols <= 12)
+    u16 wtNext[64]; s32 wtDfs[16]; u32 wtDnb[16];
+    // batch scratch for the literal gather
+    u32 bLit[64], bSrc[64];
+    // entropy state carried between blocks (zstd_compress_internal.h ZSTD_compressedBlockState_t)
+    u32 prevRep[3], nextRep[3];
+    u32 prevHufRepeat, nextHufRepeat;
+    u32 prevLL, prevOF, prevML, nextLL, nextOF, nextML;   // FSE repeat modes
+    u32 err;
+    u32 u[24];
+};
+enum { EU_nbSeq, EU_litSize, EU_lastLL, EU_cSize, EU_litCSize, EU_hType, EU_single, EU_hSize, EU_useOld,
+       EU_s0, EU_s1, EU_s2, EU_s3, EU_op, EU_tmp, EU_longType, EU_longPos, EU_raw };
+
+// packed sequence record: litLength (18 bits) | mlBase (18 bits) << 18 | offBase (28 bits) << 36
+ZSA_DEV u64 zsa_packseq(u32 ll, u32 mlBase, u32 offBase) { return (u64)ll | ((u64)mlBase << 18) | ((u64)offBase << 36); }
+ZSA_DEV u32 zsa_seq_ll(u64 s) { return (u32)s & 0x3FFFF; }
+ZSA_DEV u32 zsa_seq_ml(u64 s) { return (u32)(s >> 18) & 0x3FFFF; }
+ZSA_DEV u32 zsa_seq_of(u64 s) { return (u32)(s >> 36); }
+
+// ------------------------------------------------------------------ LSB-first bit writer (bitstream.h:154-241)
+struct ZsaBitW { u8* start; u8* p; u64 acc; u32 nb; };
+ZSA_DEV void zsa_bw_init(ZsaBitW& w, u8* dst) { w.start = w.p = dst; w.acc = 0; w.nb = 0; }
+ZSA_DEV void zsa_bw_add(ZsaBitW& w, u32 value, u32 nbBits)
+{   // nbBits <= 31; BIT_addBits masks the value
+    value &= (1u << nbBits) - 1u;
+    w.acc |= (u64)value << w.nb;
+    w.nb += nbBits;
+    while (w.nb >= 8) { *w.p++ = (u8)w.acc; w.acc >>= 8; w.nb -= 8; }
+}
+ZSA_DEV u32 zsa_bw_close(ZsaBitW& w)
+{
+    zsa_bw_add(w, 1, 1);
+    if (w.nb) { *w.p++ = (u8)w.acc; w.acc = 0; w.nb = 0; }
+    return (u32)(w.p - w.start);
+}
+
+// ------------------------------------------------------------------ hashing / counting (zstd_compress_internal.h:755-846)
+ZSA_DEV u32 zsa_hash(u64 v, u32 hBits, u32 mls)
+{   // v = MEM_readLE64(p) (only the low 32 bits matter for mls 4)
+    switch (mls) {
+    default:
+    case 4: return ((u32)v * 2654435761U) >> (32 - hBits);
+    case 5: return (u32)(((v << (64 - 40)) * 889523592379ULL) >> (64 - hBits));
+    case 6: return (u32)(((v << (64 - 48)) * 227718039650203ULL) >> (64 - hBits));
+    case 7: return (u32)(((v << (64 - 56)) * 58295818150454627ULL) >> (64 - hBits));
+    case 8: return (u32)((v * 0xCF1BBCDCB7A56463ULL) >> (64 - hBits));
+    }
+}
+ZSA_DEV u32 zsa_count(const u8* pIn, const u8* pMatch, const u8* const pInLimit)
+{   // ZSTD_count: common-prefix length, capped at pInLimit
+    const u8* const pStart = pIn;
+    while (pIn + 8 <= pInLimit) {
+        u64 const diff = zsa_ld64(pMatch) ^ zsa_ld64(pIn);
+        if (diff) return (u32)(pIn - pStart) + ((u32)__builtin_ctzll(diff) >> 3);
+        pIn += 8; pMatch += 8;
+    }
+    while (pIn < pInLimit && *pIn == *pMatch) { pIn++; pMatch++; }
+    return (u32)(pIn - pStart);
+}
+
+// ------------------------------------------------------------------ parse, no dictionary (zstd_fast.c:143-403), serial
+// `base` is the window base (index i <-> base + i); the frame starts at index 2.  Appends packed sequences
+// to seqOut, returns their number; *lastLL receives the size of the trailing literal run.
+ZSA_DEV u32 zsa_parse_fast(u32* hashTable, const ZsaEncParams& P, const u8* base, u32 dictLimit,
+                           const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL)
+{
+    u32 const hlog = P.hlog, mls = P.mml;
+    u32 const stepSize = (P.tlen > 1) ? (P.tlen + 1) : 2;      // zstd_fast.c:153, :429
+    const u8* const istart = src;
+    u32 const endIndex = (u32)(istart - base) + srcSize;
+    u32 const maxDistance = 1u << P.wlog;
+    // ZSTD_getLowestPrefixIndex (zstd_compress_internal.h:1307-1318), no loaded dictionary
+    u32 const prefixStartIndex = (endIndex - dictLimit > maxDistance) ? endIndex - maxDistance : dictLimit;
+    const u8* const prefixStart = base + prefixStartIndex;
+    const u8* const iend = istart + srcSize;
+    const u8* const ilimit = iend - 8;
+    const u8* anchor = istart;
+    const u8* ip0 = istart;
+    u32 rep1 = rep[0], rep2 = rep[1], saved1 = 0, saved2 = 0;
+    u32 nbSeq = 0;
+
+    ip0 += (ip0 == prefixStart);
+    {   u32 const curr = (u32)(ip0 - base);
+        u32 const windowLow = (curr - dictLimit > maxDistance) ? curr - maxDistance : dictLimit;
+        u32 const maxRep = curr - windowLow;
+        if (rep2 > maxRep) { saved2 = rep2; rep2 = 0; }
+        if (rep1 > maxRep) { saved1 = rep1; rep1 = 0; }
+    }
+    for (;;) {
+        u32 step = stepSize;
+        const u8* nextStep = ip0 + 128;
+        const u8* ip1 = ip0 + 1;
+        const u8* ip2 = ip0 + step;
+        const u8* ip3 = ip2 + 1;
+        u32 h0, h1, idx, current0 = 0, offcode = 0, mLength = 0;
+        const u8* match0 = base;
+        int found = 0;
+        if (ip3 >= ilimit) break;
+        h0 = zsa_hash(zsa_ld64(ip0), hlog, mls);
+        h1 = zsa_hash(zsa_ld64(ip1), hlog, mls);
+        idx = hashTable[h0];
+        do {
+            u32 const rval = zsa_ld32(ip2 - rep1);
+            current0 = (u32)(ip0 - base);
+            hashTable[h0] = current0;
+            if ((zsa_ld32(ip2) == rval) & (rep1 > 0)) {
+                ip0 = ip2;
+                match0 = ip0 - rep1;
+                mLength = ip0[-1] == match0[-1];
+                ip0 -= mLength; match0 -= mLength;
+                offcode = 1;
+                mLength += 4;
+                hashTable[h1] = (u32)(ip1 - base);
+                found = 1;
+                break;
+            }
+            if (idx >= prefixStartIndex && zsa_ld32(base + idx) == zsa_ld32(ip0)) {
+                hashTable[h1] = (u32)(ip1 - base);
+                found = 2;
+                break;
+            }
+            idx = hashTable[h1];
+            h0 = h1;
+            h1 = zsa_hash(zsa_ld64(ip2), hlog, mls);
+            ip0 = ip1; ip1 = ip2; ip2 = ip3;
+            current0 = (u32)(ip0 - base);
+            hashTable[h0] = current0;
+            if (idx >= prefixStartIndex && zsa_ld32(base + idx) == zsa_ld32(ip0)) {
+                if (step <= 4) hashTable[h1] = (u32)(ip1 - base);
+                found = 2;
+                break;
+            }
+            idx = hashTable[h1];
+            h0 = h1;
+            h1 = zsa_hash(zsa_ld64(ip2), hlog, mls);
+            ip0 = ip1; ip1 = ip2;
+            ip2 = ip0 + step;
+            ip3 = ip1 + step;
+            if (ip2 >= nextStep) { step++; nextStep += 128; }
+        } while (ip3 < ilimit);
+        if (!found) break;
+        if (found == 2) {
+            match0 = base + idx;
+            rep2 = rep1;
+            rep1 = (u32)(ip0 - match0);
+            offcode = rep1 + 3;
+            mLength = 4;
+            while (((ip0 > anchor) & (match0 > prefixStart)) && (ip0[-1] == match0[-1])) { ip0--; match0--; mLength++; }
+        }
+        mLength += zsa_count(ip0 + mLength, match0 + mLength, iend);
+        seqOut[nbSeq++] = zsa_packseq((u32)(ip0 - anchor), mLength - ZSA_MINMATCH, offcode);
+        ip0 += mLength;
+        anchor = ip0;
+        if (ip0 <= ilimit) {
+            hashTable[zsa_hash(zsa_ld64(base + current0 + 2), hlog, mls)] = current0 + 2;
+            hashTable[zsa_hash(zsa_ld64(ip0 - 2), hlog, mls)] = (u32)(ip0 - 2 - base);
+            if (rep2 > 0) {
+                while ((ip0 <= ilimit) && (zsa_ld32(ip0) == zsa_ld32(ip0 - rep2))) {
+                    u32 const rLength = zsa_count(ip0 + 4, ip0 + 4 - rep2, iend) + 4;
+                    { u32 const t = rep2; rep2 = rep1; rep1 = t; }
+                    hashTable[zsa_hash(zsa_ld64(ip0), hlog, mls)] = (u32)(ip0 - base);
+                    ip0 += rLength;
+                    seqOut[nbSeq++] = zsa_packseq(0, rLength - ZSA_MINMATCH, 1);
+                    anchor = ip0;
+                }
+            }
+        }
+    }
+    saved2 = ((saved1 != 0) && (rep1 != 0)) ? saved1 : saved2;
+    rep[0] = rep1 ? rep1 : saved1;
+    rep[1] = rep2 ? rep2 : saved2;
+    *lastLL = (u32)(iend - anchor);
+    return nbSeq;
+}
+
+// ------------------------------------------------------------------ FSE (fse_compress.c), serial helpers
+ZSA_DEV u32 zsa_fse_minTableLog(u32 srcSize, u32 maxSV)
+{
+    u32 const a = zsa_highbit32(srcSize) + 1, b = zsa_highbit32(maxSV) + 2;
+    return a < b ? a : b;
+}
+ZSA_DEV u32 zsa_fse_optimalTableLog(u32 maxTableLog, u32 srcSize, u32 maxSV, u32 minus)
+{   // fse_compress.c:357-369
+    u32 const maxBitsSrc = zsa_highbit32(srcSize - 1) - minus;
+    u32 tableLog = maxTableLog;
+    u32 const minBits = zsa_fse_minTableLog(srcSize, maxSV);
+    if (maxBitsSrc < tableLog) tableLog = maxBitsSrc;
+    if (minBits > tableLog) tableLog = minBits;
+    if (tableLog < ZSA_FSE_MIN_TABLELOG) tableLog = ZSA_FSE_MIN_TABLELOG;
+    if (tableLog > ZSA_FSE_MAX_TABLELOG) tableLog = ZSA_FSE_MAX_TABLELOG;
+    return tableLog;
+}
+// fse_compress.c:379-463 FSE_normalizeM2; returns 0 ok, 1 error
+ZSA_DEV u32 zsa_fse_normalizeM2(s16* norm, u32 tableLog, const u32* count, u32 total, u32 maxSV, s16 lowProbCount)
+{
+    const s16 NOT_YET = -2;
+    u32 s, distributed = 0, toDistribute;
+    u32 const lowThreshold = total >> tableLog;
+    u32 lowOne = (u32)(((u64)total * 3) >> (tableLog + 1));
+    for (s = 0; s <= maxSV; s++) {
+        if (count[s] == 0) { norm[s] = 0; continue; }
+        if (count[s] <= lowThreshold) { norm[s] = lowProbCount; distributed++; total -= count[s]; continue; }
+        if (count[s] <= lowOne) { norm[s] = 1; distributed++; total -= count[s]; continue; }
+        norm[s] = NOT_YET;
+    }
+    toDistribute = (1u << tableLog) - distributed;
+    if (toDistribute == 0) return 0;
+    if ((total / toDistribute) > lowOne) {
+        lowOne = (u32)(((u64)total * 3) / (toDistribute * 2));
+        for (s = 0; s <= maxSV; s++)
+            if (norm[s] == NOT_YET && count[s] <= lowOne) { norm[s] = 1; distributed++; total -= count[s]; }
+        toDistribute = (1u << tableLog) - distributed;
+    }
+    if (distributed == maxSV + 1) {
+        u32 maxV = 0, maxC = 0;
+        for (s = 0; s <= maxSV; s++) if (count[s] > maxC) { maxV = s; maxC = count[s]; }
+        norm[maxV] += (s16)toDistribute;
+        return 0;
+    }
+    if (total == 0) {
+        for (s = 0; toDistribute > 0; s = (s + 1) % (maxSV + 1))
+            if (norm[s] > 0) { toDistribute--; norm[s]++; }
+        return 0;
+    }
+    {   u64 const vStepLog = 62 - tableLog;
+        u64 const mid = ((u64)1 << (vStepLog - 1)) - 1;
+        u64 const rStep = ((((u64)1 << vStepLog) * toDistribute) + mid) / total;
+        u64 tmpTotal = mid;
+        for (s = 0; s <= maxSV; s++) {
+            if (norm[s] == NOT_YET) {
+                u64 const end = tmpTotal + ((u64)count[s] * rStep);
+                u32 const sStart = (u32)(tmpTotal >> vStepLog), sEnd = (u32)(end >> vStepLog);
+                u32 const weight = sEnd - sStart;
+                if (weight < 1) return 1;
+                norm[s] = (s16)weight;
+                tmpTotal = end;
+            }
+        }
+    }
+    return 0;
+}
+// fse_compress.c:465-525 FSE_normalizeCount; returns 0 ok (norm filled; or rle special case flagged by *rle), 1 error
+ZSA_DEV u32 zsa_fse_normalizeCount(s16* norm, u32 tableLog, const u32* count, u32 total, u32 maxSV, u32 useLowProb)
+{
+    const u32 rtb[8] = { 0, 473195, 504333, 520860, 550000, 700000, 750000, 830000 };
+    if (tableLog < ZSA_FSE_MIN_TABLELOG || tableLog > ZSA_FSE_MAX_TABLELOG) return 1;
+    if (tableLog < zsa_fse_minTableLog(total, maxSV)) return 1;
+    s16 const lowProbCount = useLowProb ? -1 : 1;
+    u64 const scale = 62 - tableLog;
+    u64 const step = ((u64)1 << 62) / total;
+    u64 const vStep = (u64)1 << (scale - 20);
+    int stillToDistribute = 1 << tableLog;
+    u32 largest = 0;
+    s16 largestP = 0;
+    u32 const lowThreshold = total >> tableLog;
+    for (u32 s = 0; s <= maxSV; s++) {
+        if (count[s] == total) return 0;
+        if (count[s] == 0) { norm[s] = 0; continue; }
+        if (count[s] <= lowThreshold) { norm[s] = lowProbCount; stillToDistribute--; }
+        else {
+            s16 proba = (s16)(((u64)count[s] * step) >> scale);
+            if (proba < 8) {
+                u64 const restToBeat = vStep * rtb[proba];
+                proba += ((u64)count[s] * step) - ((u64)proba << scale) > restToBeat;
+            }
+            if (proba > largestP) { largestP = proba; largest = s; }
+            norm[s] = proba;
+            stillToDistribute -= proba;
+        }
+    }
+    if (-stillToDistribute >= (norm[largest] >> 1)) return zsa_fse_normalizeM2(norm, tableLog, count, total, maxSV, lowProbCount);
+    norm[largest] += (s16)stillToDistribute;
+    return 0;
+}
+// fse_compress.c:234-340 FSE_writeNCount (output buffer is always large enough here); returns size, 0 on error
+ZSA_DEV u32 zsa_fse_writeNCount(u8* dst, const s16* norm, u32 maxSV, u32 tableLog)
+{
+    u8* out = dst;
+    int nbBits, remaining, threshold, bitCount = 0, previousIs0 = 0;
+    int const tableSize = 1 << tableLog;
+    u32 bitStream = 0, symbol = 0;
+    u32 const alphabetSize = maxSV + 1;
+    bitStream += (tableLog - ZSA_FSE_MIN_TABLELOG) << bitCount;
+    bitCount += 4;
+    remaining = tableSize + 1;
+    threshold = tableSize;
+    nbBits = (int)tableLog + 1;
+    while ((symbol < alphabetSize) && (remaining > 1)) {
+        if (previousIs0) {
+            u32 start = symbol;
+            while ((symbol < alphabetSize) && !norm[symbol]) symbol++;
+            if (symbol == alphabetSize) break;
+            while (symbol >= start + 24) {
+                start += 24;
+                bitStream += 0xFFFFU << bitCount;
+                out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += 2;
+                bitStream >>= 16;
+            }
+            while (symbol >= start + 3) { start += 3; bitStream += 3u << bitCount; bitCount += 2; }
+            bitStream += (symbol - start) << bitCount;
+            bitCount += 2;
+            if (bitCount > 16) { out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += 2; bitStream >>= 16; bitCount -= 16; }
+        }
+        {   int count = norm[symbol++];
+            int const max = (2 * threshold - 1) - remaining;
+            remaining -= count < 0 ? -count : count;
+            count++;
+            if (count >= threshold) count += max;
+            bitStream += (u32)count << bitCount;
+            bitCount += nbBits;
+            bitCount -= (count < max);
+            previousIs0 = (count == 1);
+            if (remaining < 1) return 0;
+            while (remaining < threshold) { nbBits--; threshold >>= 1; }
+        }
+        if (bitCount > 16) { out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += 2; bitStream >>= 16; bitCount -= 16; }
+    }
+    if (remaining != 1) return 0;
+    out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8);
+    out += (bitCount + 7) / 8;
+    return (u32)(out - dst);
+}
+// fse_compress.c:69-215 FSE_buildCTable_wksp (generic spreading)
+ZSA_DEV void zsa_fse_buildCTable(ZsaEncShared* S, u16* nextState, s32* dfs, u32* dnb, const s16* norm, u32 maxSV, u32 tableLog)
+{
+    u32 const tableSize = 1u << tableLog, tableMask = tableSize - 1, step = ZSA_FSE_TABLESTEP(tableSize);
+    u32 const maxSV1 = maxSV + 1;
+    u16* const cumul = S->cumul;
+    u8* const tableSymbol = S->tableSymbol;
+    u32 highThreshold = tableSize - 1;
+    cumul[0] = 0;
+    for (u32 u = 1; u <= maxSV1; u++) {
+        if (norm[u - 1] == -1) { cumul[u] = cumul[u - 1] + 1; tableSymbol[highThreshold--] = (u8)(u - 1); }
+        else cumul[u] = cumul[u - 1] + (u16)norm[u - 1];
+    }
+    cumul[maxSV1] = (u16)(tableSize + 1);
+    {   u32 position = 0;
+        for (u32 s = 0; s < maxSV1; s++) {
+            int const freq = norm[s];
+            for (int n = 0; n < freq; n++) {
+                tableSymbol[position] = (u8)s;
+                position = (position + step) & tableMask;
+                while (position > highThreshold) position = (position + step) & tableMask;
+            }
+        }
+    }
+    for (u32 u = 0; u < tableSize; u++) { u32 const sy = tableSymbol[u]; nextState[cumul[sy]++] = (u16)(tableSize + u); }
+    {   u32 total = 0;
+        for (u32 s = 0; s <= maxSV; s++) {
+            int const nc = norm[s];
+            if (nc == 0) { dnb[s] = ((tableLog + 1) << 16) - (1u << tableLog); dfs[s] = 0; }
+            else if (nc == -1 || nc == 1) { dnb[s] = (tableLog << 16) - (1u << tableLog); dfs[s] = (s32)(total - 1); total++; }
+            else {
+                u32 const maxBitsOut = tableLog - zsa_highbit32((u32)nc - 1);
+                u32 const minStatePlus = (u32)nc << maxBitsOut;
+                dnb[s] = (maxBitsOut << 16) - minStatePlus;
+                dfs[s] = (s32)(total - (u32)nc);
+                total += (u32)nc;
+            }
+        }
+    }
+}
+// FSE encoder state (fse.h:437-476)
+struct ZsaFseCState { u32 value; const u16* next; const s32* dfs; const u32* dnb; u32 stateLog; };
+ZSA_DEV void zsa_fse_initCState2(ZsaFseCState& st, const u16* next, const s32* dfs, const u32* dnb, u32 tableLog, u32 symbol)
+{
+    u32 const nbBitsOut = (dnb[symbol] + (1u << 15)) >> 16;
+    st.next = next; st.dfs = dfs; st.dnb = dnb; st.stateLog = tableLog;
+    st.value = (nbBitsOut << 16) - dnb[symbol];
+    st.value = next[(s32)(st.value >> nbBitsOut) + dfs[symbol]];
+}
+ZSA_DEV void zsa_fse_encodeSymbol(ZsaBitW& w, ZsaFseCState& st, u32 symbol)
+{
+    u32 const nbBitsOut = (st.value + st.dnb[symbol]) >> 16;
+    zsa_bw_add(w, st.value, nbBitsOut);
+    st.value = st.next[(s32)(st.value >> nbBitsOut) + st.dfs[symbol]];
+}
+
+// ------------------------------------------------------------------ Huffman table construction (huf_compress.c), serial
+ZSA_DEV u32 zsa_huf_bucket(u32 count) { return (count < 166) ? count : zsa_highbit32(count) + 158; }
+ZSA_DEV void zsa_huf_insertionSort(ZsaHufNode* a, int low, int high)
+{   // huf_compress.c:531-544
+    int const size = high - low + 1;
+    a += low;
+    for (int i = 1; i < size; ++i) {
+        ZsaHufNode const key = a[i];
+        int j = i - 1;
+        while (j >= 0 && a[j].count < key.count) { a[j + 1] = a[j]; j--; }
+        a[j + 1] = key;
+    }
+}
+ZSA_DEV int zsa_huf_partition(ZsaHufNode* a, int low, int high)
+{   // huf_compress.c:547-562
+    u32 const pivot = a[high].count;
+    int i = low - 1;
+    for (int j = low; j < high; j++) {
+        if (a[j].count > pivot) { i++; ZsaHufNode const t = a[i]; a[i] = a[j]; a[j] = t; }
+    }
+    { ZsaHufNode const t = a[i + 1]; a[i + 1] = a[high]; a[high] = t; }
+    return i + 1;
+}
+ZSA_DEV void zsa_huf_quickSort(ZsaHufNode* a, int low0, int high0)
+{   // huf_compress.c:567-583 HUF_simpleQuickSort.  Device code has no recursion: the call stack is explicit.
+    // A frame is one activation; `fresh` marks an activation that has not yet taken its "< 8 -> insertion sort"
+    // test.  As in the reference, an activation recurses into the SMALLER side and keeps partitioning the larger
+    // one itself (without re-testing the threshold), so the depth is bounded by log2(256).
+    int lo[12], hi[12], fresh[12], sp = 1;
+    lo[0] = low0; hi[0] = high0; fresh[0] = 1;
+    while (sp > 0) {
+        int const f = sp - 1;
+        if (fresh[f]) {
+            fresh[f] = 0;
+            if (hi[f] - lo[f] < 8) { zsa_huf_insertionSort(a, lo[f], hi[f]); sp--; continue; }
+        }
+        if (lo[f] < hi[f]) {
+            int const idx = zsa_huf_partition(a, lo[f], hi[f]);
+            int cl, ch;
+            if (idx - lo[f] < hi[f] - idx) { cl = lo[f]; ch = idx - 1; lo[f] = idx + 1; }
+            else { cl = idx + 1; ch = hi[f]; hi[f] = idx - 1; }
+            lo[sp] = cl; hi[sp] = ch; fresh[sp] = 1; sp++;
+        } else sp--;
+    }
+}
+// huf_compress.c:596-641 HUF_sort
+ZSA_DEV void zsa_huf_sort(ZsaEncShared* S, ZsaHufNode* node, const u32* count, u32 maxSV)
+{
+    u32 const maxSV1 = maxSV + 1;
+    for (u32 n = 0; n < 192; n++) { S->rpBase[n] = 0; S->rpCurr[n] = 0; }
+    for (u32 n = 0; n < maxSV1; ++n) S->rpBase[zsa_huf_bucket(count[n])]++;
+    for (u32 n = 191; n > 0; --n) { S->rpBase[n - 1] += S->rpBase[n]; S->rpCurr[n - 1] = S->rpBase[n - 1]; }
+    for (u32 n = 0; n < maxSV1; ++n) {
+        u32 const c = count[n], r = zsa_huf_bucket(c) + 1, pos = S->rpCurr[r]++;
+        node[pos].count = c; node[pos].byte = (u8)n;
+    }
+    for (u32 n = 166; n < 191; ++n) {
+        int const bucketSize = (int)S->rpCurr[n] - (int)S->rpBase[n];
+        if (bucketSize > 1) zsa_huf_quickSort(node + S->rpBase[n], 0, bucketSize - 1);
+    }
+}
+// huf_compress.c:657-694 HUF_buildTree
+ZSA_DEV int zsa_huf_buildTree(ZsaHufNode* node, u32 maxSV)
+{
+    ZsaHufNode* const node0 = node - 1;
+    int nonNullRank = (int)maxSV, lowS, lowN, nodeNb = 256, nodeRoot;
+    while (node[nonNullRank].count == 0) nonNullRank--;
+    lowS = nonNullRank; nodeRoot = nodeNb + lowS - 1; lowN = nodeNb;
+    node[nodeNb].count = node[lowS].count + node[lowS - 1].count;
+    node[lowS].parent = node[lowS - 1].parent = (u16)nodeNb;
+    nodeNb++; lowS -= 2;
+    for (int n = nodeNb; n <= nodeRoot; n++) node[n].count = 1u << 30;
+    node0[0].count = 1u << 31;
+    while (nodeNb <= nodeRoot) {
+        int const n1 = (node[lowS].count < node[lowN].count) ? lowS-- : lowN++;
+        int const n2 = (node[lowS].count < node[lowN].count) ? lowS-- : lowN++;
+        node[nodeNb].count = node[n1].count + node[n2].count;
+        node[n1].parent = node[n2].parent = (u16)nodeNb;
+        nodeNb++;
+    }
+    node[nodeRoot].nbBits = 0;
+    for (int n = nodeRoot - 1; n >= 256; n--) node[n].nbBits = node[node[n].parent].nbBits + 1;
+    for (int n = 0; n <= nonNullRank; n++) node[n].nbBits = node[node[n].parent].nbBits + 1;
+    return nonNullRank;
+}
+// huf_compress.c:352-474 HUF_setMaxHeight
+ZSA_DEV u32 zsa_huf_setMaxHeight(ZsaHufNode* node, u32 lastNonNull, u32 targetNbBits)
+{
+    u32 const largestBits = node[lastNonNull].nbBits;
+    if (largestBits <= targetNbBits) return largestBits;
+    int totalCost = 0;
+    u32 const baseCost = 1u << (largestBits - targetNbBits);
+    int n = (int)lastNonNull;
+    while (node[n].nbBits > targetNbBits) {
+        totalCost += (int)(baseCost - (1u << (largestBits - node[n].nbBits)));
+        node[n].nbBits = (u8)targetNbBits;
+        n--;
+    }
+    while (node[n].nbBits == targetNbBits) --n;
+    totalCost >>= (largestBits - targetNbBits);
+    u32 const noSymbol = 0xF0F0F0F0;
+    u32 rankLast[ZSA_HUF_TABLELOG_MAX + 2];
+    for (u32 i = 0; i < ZSA_HUF_TABLELOG_MAX + 2; i++) rankLast[i] = noSymbol;
+    {   u32 currentNbBits = targetNbBits;
+        for (int pos = n; pos >= 0; pos--) {
+            if (node[pos].nbBits >= currentNbBits) continue;
+            currentNbBits = node[pos].nbBits;
+            rankLast[targetNbBits - currentNbBits] = (u32)pos;
+        }
+    }
+    while (totalCost > 0) {
+        u32 nBitsToDecrease = zsa_highbit32((u32)totalCost) + 1;
+        for (; nBitsToDecrease > 1; nBitsToDecrease--) {
+            u32 const highPos = rankLast[nBitsToDecrease], lowPos = rankLast[nBitsToDecrease - 1];
+            if (highPos == noSymbol) continue;
+            if (lowPos == noSymbol) break;
+            if (node[highPos].count <= 2 * node[lowPos].count) break;
+        }
+        while ((nBitsToDecrease <= ZSA_HUF_TABLELOG_MAX) && (rankLast[nBitsToDecrease] == noSymbol)) nBitsToDecrease++;
+        totalCost -= 1 << (nBitsToDecrease - 1);
+        node[rankLast[nBitsToDecrease]].nbBits++;
+        if (rankLast[nBitsToDecrease - 1] == noSymbol) rankLast[nBitsToDecrease - 1] = rankLast[nBitsToDecrease];
+        if (rankLast[nBitsToDecrease] == 0) rankLast[nBitsToDecrease] = noSymbol;
+        else {
+            rankLast[nBitsToDecrease]--;
+            if (node[rankLast[nBitsToDecrease]].nbBits != targetNbBits - nBitsToDecrease) rankLast[nBitsToDecrease] = noSymbol;
+        }
+    }
+    while (totalCost < 0) {
+        if (rankLast[1] == noSymbol) {
+            while (node[n].nbBits == targetNbBits) n--;
+            node[n + 1].nbBits--;
+            rankLast[1] = (u32)(n + 1);
+            totalCost++;
+            continue;
+        }
+        node[rankLast[1] + 1].nbBits--;
+        rankLast[1]++;
+        totalCost++;
+    }
+    return targetNbBits;
+}
+// huf_compress.c:730-766 HUF_buildCTable_wksp + :706-728; returns maxNbBits (0 on error)
+ZSA_DEV u32 zsa_huf_buildCTable(ZsaEncShared* S, ZsaHufCT* ct, const u32* count, u32 maxSV, u32 maxNbBits)
+{
+    ZsaHufNode* const node = S->node + 1;
+    for (u32 i = 0; i < 2 * 256 + 2; i++) { S->node[i].count = 0; S->node[i].parent = 0; S->node[i].byte = 0; S->node[i].nbBits = 0; }
+    zsa_huf_sort(S, node, count, maxSV);
+    int const nonNullRank = zsa_huf_buildTree(node, maxSV);
+    maxNbBits = zsa_huf_setMaxHeight(node, (u32)nonNullRank, maxNbBits);
+    if (maxNbBits > ZSA_HUF_TABLELOG_MAX) return 0;
+    u16 nbPerRank[ZSA_HUF_TABLELOG_MAX + 1], valPerRank[ZSA_HUF_TABLELOG_MAX + 1];
+    for (u32 i = 0; i <= ZSA_HUF_TABLELOG_MAX; i++) { nbPerRank[i] = 0; valPerRank[i] = 0; }
+    for (int n = 0; n <= nonNullRank; n++) nbPerRank[node[n].nbBits]++;
+    {   u16 min = 0;
+        for (int n = (int)maxNbBits; n > 0; n--) { valPerRank[n] = min; min += nbPerRank[n]; min >>= 1; }
+    }
+    for (u32 n = 0; n < 256; n++) { ct->nbBits[n] = 0; ct->val[n] = 0; }
+    for (u32 n = 0; n <= maxSV; n++) ct->nbBits[node[n].byte] = node[n].nbBits;
+    for (u32 n = 0; n <= maxSV; n++) { u32 const b = ct->nbBits[n]; u16 const v = valPerRank[b]++; ct->val[n] = b ? v : 0; }
+    return maxNbBits;
+}
+// huf_compress.c:147-187 HUF_compressWeights; returns size; 0 "not compressible", 1 "rle", 0xFFFFFFFF error
+ZSA_DEV u32 zsa_huf_compressWeights(ZsaEncShared* S, u8* dst, const u8* weights, u32 wtSize)
+{
+    u8* op = dst;
+    u32 maxSV = ZSA_HUF_TABLELOG_MAX, tableLog = 6;
+    u32 cnt[ZSA_HUF_TABLELOG_MAX + 1];
+    s16 norm[ZSA_HUF_TABLELOG_MAX + 1];
+    if (wtSize <= 1) return 0;
+    for (u32 i = 0; i <= ZSA_HUF_TABLELOG_MAX; i++) cnt[i] = 0;
+    for (u32 i = 0; i < wtSize; i++) cnt[weights[i]]++;
+    while (!cnt[maxSV]) maxSV--;
+    {   u32 maxCount = 0;
+        for (u32 s = 0; s <= maxSV; s++) if (cnt[s] > maxCount) maxCount = cnt[s];
+        if (maxCount == wtSize) return 1;
+        if (maxCount == 1) return 0;
+    }
+    tableLog = zsa_fse_optimalTableLog(tableLog, wtSize, maxSV, 2);
+    if (zsa_fse_normalizeCount(norm, tableLog, cnt, wtSize, maxSV, 0)) return 0xFFFFFFFFu;
+    {   u32 const h = zsa_fse_writeNCount(op, norm, maxSV, tableLog);
+        if (h == 0) return 0xFFFFFFFFu;
+        op += h;
+    }
+    zsa_fse_buildCTable(S, S->wtNext, S->wtDfs, S->wtDnb, norm, maxSV, tableLog);
+    {   // fse_compress.c:551-608 FSE_compress_usingCTable_generic
+        const u8* ip = weights + wtSize;
+        u32 srcSize = wtSize;
+        ZsaBitW w;
+        ZsaFseCState s1, s2;
+        if (srcSize <= 2) return 0;
+        zsa_bw_init(w, op);
+        if (srcSize & 1) {
+            zsa_fse_initCState2(s1, S->wtNext, S->wtDfs, S->wtDnb, tableLog, *--ip);
+            zsa_fse_initCState2(s2, S->wtNext, S->wtDfs, S->wtDnb, tableLog, *--ip);
+            zsa_fse_encodeSymbol(w, s1, *--ip);
+        } else {
+            zsa_fse_initCState2(s2, S->wtNext, S->wtDfs, S->wtDnb, tableLog, *--ip);
+            zsa_fse_initCState2(s1, S->wtNext, S->wtDfs, S->wtDnb, tableLog, *--ip);
+        }
+        srcSize -= 2;
+        if (srcSize & 2) { zsa_fse_encodeSymbol(w, s2, *--ip); zsa_fse_encodeSymbol(w, s1, *--ip); }
+        while (ip > weights) {
+            zsa_fse_encodeSymbol(w, s2, *--ip); zsa_fse_encodeSymbol(w, s1, *--ip);
+            zsa_fse_encodeSymbol(w, s2, *--ip); zsa_fse_encodeSymbol(w, s1, *--ip);
+        }
+        zsa_bw_add(w, s2.value, s2.stateLog);
+        zsa_bw_add(w, s1.value, s1.stateLog);
+        op += zsa_bw_close(w);
+    }
+    return (u32)(op - dst);
+}
+// huf_compress.c:230-268 HUF_writeCTable_wksp; returns header size, 0 on error
+ZSA_DEV u32 zsa_huf_writeCTable(ZsaEncShared* S, u8* dst, const ZsaHufCT* ct, u32 maxSV, u32 huffLog)
+{
+    u8 bitsToWeight[ZSA_HUF_TABLELOG_MAX + 1];
+    u8* const huffWeight = S->huffWeight;
+    bitsToWeight[0] = 0;
+    for (u32 n = 1; n < huffLog + 1; n++) bitsToWeight[n] = (u8)(huffLog + 1 - n);
+    for (u32 n = 0; n < maxSV; n++) huffWeight[n] = bitsToWeight[ct->nbBits[n]];
+    {   u32 const hSize = zsa_huf_compressWeights(S, dst + 1, huffWeight, maxSV);
+        if (hSize == 0xFFFFFFFFu) return 0;
+        if ((hSize > 1) & (hSize < maxSV / 2)) { dst[0] = (u8)hSize; return hSize + 1; }
+    }
+    if (maxSV > (256 - 128)) return 0;
+    dst[0] = (u8)(128 + (maxSV - 1));
+    huffWeight[maxSV] = 0;
+    for (u32 n = 0; n < maxSV; n += 2) dst[(n / 2) + 1] = (u8)((huffWeight[n] << 4) + huffWeight[n + 1]);
+    return ((maxSV + 1) / 2) + 1;
+}
+ZSA_DEV u32 zsa_huf_estimate(const ZsaHufCT* ct, const u32* count, u32 maxSV)
+{   // huf_compress.c:768-777
+    u64 nbBits = 0;
+    for (u32 s = 0; s <= maxSV; ++s) nbBits += (u64)ct->nbBits[s] * count[s];
+    return (u32)(nbBits >> 3);
+}
+// one Huffman stream, symbols last -> first, end mark (huf_compress.c:1023-1086, :941-950); run by one lane
+ZSA_DEV u32 zsa_huf_encode1X(u8* dst, const u8* src, u32 srcSize, const ZsaHufCT* ct)
+{
+    ZsaBitW w;
+    zsa_bw_init(w, dst);
+    for (u32 n = srcSize; n > 0; ) { u32 const s = src[--n]; zsa_bw_add(w, ct->val[s], ct->nbBits[s]); }
+    return zsa_bw_close(w);
+}
+
+// all-lane histogram of bytes into S->count[0..255] (hist.c:30-165): exact counts
+ZSA_DEV void zsa_hist_bytes(ZsaEncShared* S, const u8* src, u32 n, int lane)
+{
+    for (u32 i = (u32)lane; i < 256; i += ZSA_WAVE) S->count[i] = 0;
+    wv_sync();
+    for (u32 i = (u32)lane; i < n; i += ZSA_WAVE) wv_atomic_add_lds(&S->count[src[i]], 1);
+    wv_sync();
+}
+
+// ------------------------------------------------------------------ literals section (zstd_compress_literals.c:130-236)
+// Writes the section at dst; returns its size (uniform).  `tmp` is global scratch of >= litSize + 64 bytes.
+ZSA_DEV u32 zsa_noCompressLiterals(u8* dst, const u8* lit, u32 litSize, int lane)
+{   // zstd_compress_literals.c:40-67
+    u32 const flSize = 1 + (litSize > 31) + (litSize > 4095);
+    if (lane == 0) {
+        if (flSize == 1) dst[0] = (u8)(zsa_set_basic + (litSize << 3));
+        else if (flSize == 2) zsa_st16(dst, zsa_set_basic + (1 << 2) + (litSize << 4));
+        else zsa_st24(dst, zsa_set_basic + (3 << 2) + (litSize << 4));
+    }
+    for (u32 i = (u32)lane; i < litSize; i += ZSA_WAVE) dst[flSize + i] = lit[i];
+    return flSize + litSize;
+}
+ZSA_DEV u32 zsa_compressLiterals(ZsaEncShared* S, u8* dst, const u8* lit, u32 litSize, u8* tmp,
+                                 int disableLiteralCompression, int suspectUncompressible, int lane)
+{
+    u32 const lhSize = 3 + (litSize >= 1024) + (litSize >= 16384);
+    // nextHuf := prevHuf (:153)
+    for (u32 i = (u32)lane; i < 256; i += ZSA_WAVE) { S->hufNext.nbBits[i] = S->hufPrev.nbBits[i]; S->hufNext.val[i] = S->hufPrev.val[i]; }
+    if (lane == 0) S->nextHufRepeat = S->prevHufRepeat;
+    wv_sync();
+    u32 const prevRepeat = S->prevHufRepeat;
+    u32 const mintc = (prevRepeat == zsa_rep_valid) ? 6 : 64;      // :115-128, strategy fast
+    if (disableLiteralCompression || litSize < mintc) return zsa_noCompressLiterals(dst, lit, litSize, lane);
+
+    u32 singleStream = litSize < 256;
+    if (prevRepeat == zsa_rep_valid && lhSize == 3) singleStream = 1;
+    int const preferRepeat = (litSize <= 1024);
+    u8* const ostart = dst + lhSize;
+
+    // ---- huf_compress.c:1298-1406 HUF_compress_internal
+    // decision: 0 -> not compressible (raw), 1 -> rle, 2 -> encode with old table, 3 -> encode with new table (header written)
+    u32 decision = 0xFF;
+    if (preferRepeat && prevRepeat == zsa_rep_valid) decision = 2;
+    if (decision == 0xFF && suspectUncompressible && litSize >= 4096 * 10) {
+        u32 largestTotal = 0;
+        zsa_hist_bytes(S, lit, 4096, lane);
+        {   u32 m = 0; for (u32 i = (u32)lane; i < 256; i += ZSA_WAVE) m = S->count[i] > m ? S->count[i] : m; largestTotal = wv_reduce_max(m); }
+        wv_sync();
+        zsa_hist_bytes(S, lit + litSize - 4096, 4096, lane);
+        {   u32 m = 0; for (u32 i = (u32)lane; i < 256; i += ZSA_WAVE) m = S->count[i] > m ? S->count[i] : m; largestTotal += wv_reduce_max(m); }
+        wv_sync();
+        if (largestTotal <= ((2 * 4096) >> 7) + 4) decision = 0;
+    }
+    u32 maxSV = 255;
+    if (decision == 0xFF) {
+        zsa_hist_bytes(S, lit, litSize, lane);
+        u32 m = 0, top = 0;
+        for (u32 i = (u32)lane; i < 256; i += ZSA_WAVE) { u32 const c = S->count[i]; if (c > m) m = c; if (c) top = i; }
+        u32 const largest = wv_reduce_max(m);
+        maxSV = wv_reduce_max(top);
+        if (largest == litSize) decision = 1;
+        else if (largest <= (litSize >> 7) + 4) decision = 0;
+    }
+    if (decision == 0xFF) {
+        if (lane == 0) {
+            u32 repeat = prevRepeat, dec = 3, hSize = 0;
+            if (repeat == zsa_rep_check) {   // HUF_validateCTable (:779-787)
+                u32 bad = 0;
+                for (u32 s = 0; s <= maxSV; ++s) bad |= (S->count[s] != 0) & (S->hufPrev.nbBits[s] == 0);
+                if (bad) repeat = zsa_rep_none;
+            }
+            if (preferRepeat && repeat != zsa_rep_none) dec = 2;
+            else {
+                u32 huffLog = zsa_fse_optimalTableLog(11, litSize, maxSV, 1);
+                u32 const maxBits = zsa_huf_buildCTable(S, &S->hufNext, S->count, maxSV, huffLog);
+                if (maxBits == 0) dec = 0;   // error -> literals stored raw (zstd_compress_literals.c:189)
+                else {
+                    huffLog = maxBits;
+                    hSize = zsa_huf_writeCTable(S, ostart, &S->hufNext, maxSV, huffLog);
+                    if (hSize == 0) dec = 0;
+                    else {
+                        if (repeat != zsa_rep_none) {
+                            u32 const oldSize = zsa_huf_estimate(&S->hufPrev, S->count, maxSV);
+                            u32 const newSize = zsa_huf_estimate(&S->hufNext, S->count, maxSV);
+                            if (oldSize <= hSize + newSize || hSize + 12 >= litSize) dec = 2;
+                        }
+                        if (dec == 3 && hSize + 12 >= litSize) dec = 0;
+                        if (dec == 3) repeat = zsa_rep_none;
+                    }
+                }
+            }
+            S->u[EU_useOld] = dec; S->u[EU_hSize] = (dec == 3) ? hSize : 0; S->u[EU_tmp] = repeat;
+        }
+        wv_sync();
+        decision = S->u[EU_useOld];
+    } else {
+        if (lane == 0) { S->u[EU_hSize] = 0; S->u[EU_tmp] = prevRepeat; }
+        wv_sync();
+    }
+    u32 const hSize = S->u[EU_hSize];
+    u32 const repeatAfter = S->u[EU_tmp];
+    u32 cLitSize = 0;   // 0 -> raw
+    if (decision == 1) cLitSize = 1;
+    else if (decision >= 2) {
+        const ZsaHufCT* const ct = (decision == 2) ? &S->hufPrev : &S->hufNext;
+        u8* const op = ostart + hSize;
+        u32 total = 0;
+        if (singleStream) {
+            if (lane == 0) S->u[EU_s0] = zsa_huf_encode1X(op, lit, litSize, ct);
+            wv_sync();
+            total = S->u[EU_s0];
+        } else if (litSize >= 12) {
+            // huf_compress.c:1135-1183: 6-byte jump table, 4 segments of (n+3)/4; each lane packs one stream into tmp
+            u32 const segmentSize = (litSize + 3) / 4;
+            u32 const segBound = segmentSize + (segmentSize >> 1) + 16;     // 11 bits/symbol worst case
+            if (lane < 4) {
+                u32 const beg = (u32)lane * segmentSize;
+                u32 const len = (lane == 3) ? litSize - 3 * segmentSize : segmentSize;
+                S->u[EU_s0 + lane] = zsa_huf_encode1X(tmp + (u32)lane * segBound, lit + beg, len, ct);
+            }
+            wv_sync();
+            u32 const c0 = S->u[EU_s0], c1 = S->u[EU_s1], c2 = S->u[EU_s2], c3 = S->u[EU_s3];
+            if (c0 > 65535 || c1 > 65535 || c2 > 65535 || c3 > 65535) total = 0;
+            else {
+                if (lane == 0) { zsa_st16(op, c0); zsa_st16(op + 2, c1); zsa_st16(op + 4, c2); }
+                for (u32 i = (u32)lane; i < c0; i += ZSA_WAVE) op[6 + i] = tmp[i];
+                for (u32 i = (u32)lane; i < c1; i += ZSA_WAVE) op[6 + c0 + i] = tmp[segBound + i];
+                for (u32 i = (u32)lane; i < c2; i += ZSA_WAVE) op[6 + c0 + c1 + i] = tmp[2 * segBound + i];
+                for (u32 i = (u32)lane; i < c3; i += ZSA_WAVE) op[6 + c0 + c1 + c2 + i] = tmp[3 * segBound + i];
+                total = 6 + c0 + c1 + c2 + c3;
+            }
+        }
+        // huf_compress.c:1192-1207 HUF_compressCTable_internal
+        if (total == 0) cLitSize = 0;
+        else if (hSize + total >= litSize - 1) cLitSize = 0;
+        else cLitSize = hSize + total;
+    }
+    wv_sync();
+    u32 hType = zsa_set_compressed;
+    if (decision >= 1 && repeatAfter != zsa_rep_none) hType = zsa_set_repeat;     // zstd_compress_literals.c:181-185
+    if (decision == 0 && repeatAfter != zsa_rep_none) hType = zsa_set_repeat;
+    {   u32 const minGain = (litSize >> 6) + 2;
+        if (cLitSize == 0 || cLitSize >= litSize - minGain) {
+            // restore nextHuf := prevHuf (:190)
+            for (u32 i = (u32)lane; i < 256; i += ZSA_WAVE) { S->hufNext.nbBits[i] = S->hufPrev.nbBits[i]; S->hufNext.val[i] = S->hufPrev.val[i]; }
+            wv_sync();
+            return zsa_noCompressLiterals(dst, lit, litSize, lane);
+        }
+    }
+    if (cLitSize == 1) {   // :193-202 (litSize >= 64 here unless repeat-valid path; then check bytes)
+        u32 identical = 1;
+        if (litSize < 8) { for (u32 i = 1; i < litSize; i++) if (lit[i] != lit[0]) identical = 0; }
+        if (litSize >= 8 || identical) {
+            for (u32 i = (u32)lane; i < 256; i += ZSA_WAVE) { S->hufNext.nbBits[i] = S->hufPrev.nbBits[i]; S->hufNext.val[i] = S->hufPrev.val[i]; }
+            wv_sync();
+            u32 const flSize = 1 + (litSize > 31) + (litSize > 4095);   // zstd_compress_literals.c:82-108
+            if (lane == 0) {
+                if (flSize == 1) dst[0] = (u8)(zsa_set_rle + (litSize << 3));
+                else if (flSize == 2) zsa_st16(dst, zsa_set_rle + (1 << 2) + (litSize << 4));
+                else zsa_st24(dst, zsa_set_rle + (3 << 2) + (litSize << 4));
+                dst[flSize] = lit[0];
+            }
+            return flSize + 1;
+        }
+    }
+    if (decision == 2) {
+        // the old table stays: nextHuf must hold prevHuf (it was overwritten if a new table was built and rejected)
+        for (u32 i = (u32)lane; i < 256; i += ZSA_WAVE) { S->hufNext.nbBits[i] = S->hufPrev.nbBits[i]; S->hufNext.val[i] = S->hufPrev.val[i]; }
+    }
+    if (lane == 0) {
+        if (hType == zsa_set_compressed) S->nextHufRepeat = zsa_rep_check;
+        if (lhSize == 3) zsa_st24(dst, hType + ((u32)(!singleStream) << 2) + (litSize << 4) + (cLitSize << 14));
+        else if (lhSize == 4) zsa_st32(dst, hType + (2 << 2) + (litSize << 4) + (cLitSize << 18));
+        else { zsa_st32(dst, hType + (3 << 2) + (litSize << 4) + (cLitSize << 22)); dst[4] = (u8)(cLitSize >> 10); }
+    }
+    wv_sync();
+    return lhSize + cLitSize;
+}
+
+// ------------------------------------------------------------------ sequences section
+ZSA_DEV u32 zsa_LLcode(u32 ll)
+{   // zstd_compress_internal.h:523-535
+    if (ll > 63) return zsa_highbit32(ll) + 19;
+    if (ll < 16) return ll;
+    if (ll < 24) return 16 + ((ll - 16) >> 1);
+    if (ll < 32) return 20 + ((ll - 24) >> 2);
+    if (ll < 48) return 22 + ((ll - 32) >> 3);
+    return 24;
+}
+ZSA_DEV u32 zsa_MLcode(u32 mlBase)
+{   // zstd_compress_internal.h:540-552
+    if (mlBase > 127) return zsa_highbit32(mlBase) + 36;
+    if (mlBase < 32) return mlBase;
+    if (mlBase < 40) return 32 + ((mlBase - 32) >> 1);
+    if (mlBase < 48) return 36 + ((mlBase - 40) >> 2);
+    if (mlBase < 64) return 38 + ((mlBase - 48) >> 3);
+    if (mlBase < 96) return 40 + ((mlBase - 64) >> 4);
+    return 42;
+}
+// zstd_compress_sequences.c:157-236, strategy ZSTD_fast branch; serial
+ZSA_DEV u32 zsa_selectEncodingType(u32* repeatMode, u32 mostFrequent, u32 nbSeq, u32 defaultNormLog, int isDefaultAllowed)
+{
+    if (mostFrequent == nbSeq) {
+        *repeatMode = zsa_rep_none;
+        if (isDefaultAllowed && nbSeq <= 2) return zsa_set_basic;
+        return zsa_set_rle;
+    }
+    if (isDefaultAllowed) {
+        u32 const dynamicFse_nbSeq_min = ((1u << defaultNormLog) * 9) >> 3;
+        if ((*repeatMode == zsa_rep_valid) && (nbSeq < 1000)) return zsa_set_repeat;
+        if ((nbSeq < dynamicFse_nbSeq_min) || (mostFrequent < (nbSeq >> (defaultNormLog - 1)))) {
+            *repeatMode = zsa_rep_none;
+            return zsa_set_basic;
+        }
+    }
+    *repeatMode = zsa_rep_check;
+    return zsa_set_compressed;
+}
+// zstd_compress_sequences.c:243-289 ZSTD_buildCTable; serial.  kind 0 LL, 1 OF, 2 ML.  Returns header bytes, sets *fail.
+ZSA_DEV u32 zsa_buildSeqCTable(ZsaEncShared* S, u8* dst, ZsaFseCT* ct, int kind, u32 type, u32* count, u32 max,
+                               u32 lastCode, u32 firstCode, u32 nbSeq, const ZsaFseCT* dictTable, u32* fail)
+{
+    u32 const FSELog = kind == 1 ? ZSA_OffFSELog : 9;
+    switch (type) {
+    case zsa_set_rle:
+        ct->tableLog = 0; ct->nextState[0] = 0; ct->nextState[1] = 0; ct->dnb[max] = 0; ct->dfs[max] = 0;
+        *dst = (u8)firstCode;
+        return 1;
+    case zsa_set_repeat:
+        if (dictTable) {
+            for (u32 i = 0; i < 512; i++) ct->nextState[i] = dictTable->nextState[i];
+            for (u32 i = 0; i <= ZSA_MaxSeq; i++) { ct->dfs[i] = dictTable->dfs[i]; ct->dnb[i] = dictTable->dnb[i]; }
+            ct->tableLog = dictTable->tableLog;
+        }
+        return 0;
+    case zsa_set_basic: {
+        u32 const dmax = kind == 0 ? ZSA_MaxLL : (kind == 1 ? ZSA_DefaultMaxOff : ZSA_MaxML);
+        u32 const dlog = kind == 1 ? ZSA_OF_DEFAULTNORMLOG : 6;
+        for (u32 s = 0; s <= dmax; s++)
+            S->norm[s] = (s16)(kind == 0 ? zsa_LL_defaultNorm(s) : (kind == 1 ? zsa_OF_defaultNorm(s) : zsa_ML_defaultNorm(s)));
+        zsa_fse_buildCTable(S, ct->nextState, ct->dfs, ct->dnb, S->norm, dmax, dlog);
+        ct->tableLog = dlog;
+        return 0; }
+    default: {
+        u32 nbSeq_1 = nbSeq;
+        u32 const tableLog = zsa_fse_optimalTableLog(FSELog, nbSeq, max, 2);
+        if (count[lastCode] > 1) { count[lastCode]--; nbSeq_1--; }
+        if (zsa_fse_normalizeCount(S->norm, tableLog, count, nbSeq_1, max, nbSeq_1 >= 2048)) { *fail = 1; return 0; }
+        u32 const NCountSize = zsa_fse_writeNCount(dst, S->norm, max, tableLog);
+        if (NCountSize == 0) { *fail = 1; return 0; }
+        zsa_fse_buildCTable(S, ct->nextState, ct->dfs, ct->dnb, S->norm, max, tableLog);
+        ct->tableLog = tableLog;
+        return NCountSize; }
+    }
+}
+
+// Entropy stage of one block: zstd_compress.c:2831-2986.  seq/nbSeq and the gathered literals are in global
+// scratch.  Returns the block body size, 0 for "store raw"; S->err on internal failure.
+ZSA_DEV u32 zsa_entropyCompress(ZsaEncShared* S, const u64* seq, u32 nbSeq, const u8* lit, u32 litSize,
+                                u8* dst, u32 srcSize, u8* tmp, int literalsDisabled, const ZsaCDictDev* cd, int lane)
+{
+    u8* op = dst;
+    {   int const suspect = (nbSeq == 0) || (litSize / nbSeq >= 20);
+        op += zsa_compressLiterals(S, op, lit, litSize, tmp, literalsDisabled, suspect, lane);
+    }
+    wv_sync();
+    if (lane == 0) {
+        u8* p = op;
+        if (nbSeq < 128) *p++ = (u8)nbSeq;
+        else if (nbSeq < ZSA_LONGNBSEQ) { p[0] = (u8)((nbSeq >> 8) + 0x80); p[1] = (u8)nbSeq; p += 2; }
+        else { p[0] = 0xFF; zsa_st16(p + 1, nbSeq - ZSA_LONGNBSEQ); p += 3; }
+        S->u[EU_tmp] = (u32)(p - op);
+        S->nextLL = S->prevLL; S->nextOF = S->prevOF; S->nextML = S->prevML;
+    }
+    wv_sync();
+    op += S->u[EU_tmp];
+    if (nbSeq != 0) {
+        u8* const seqHead = op++;
+        u32 types[3], lastCountSize = 0;
+        u64 const lastSeq = seq[nbSeq - 1], firstSeq = seq[0];
+        for (int kind = 0; kind < 3; kind++) {
+            // histogram of the codes of this kind (hist.c; ZSTD_seqToCodes zstd_compress.c:2637-2663)
+            for (u32 i = (u32)lane; i <= ZSA_MaxSeq; i += ZSA_WAVE) S->count[i] = 0;
+            wv_sync();
+            for (u32 i = (u32)lane; i < nbSeq; i += ZSA_WAVE) {
+                u64 const s = seq[i];
+                u32 const c = kind == 0 ? zsa_LLcode(zsa_seq_ll(s)) : (kind == 1 ? zsa_highbit32(zsa_seq_of(s)) : zsa_MLcode(zsa_seq_ml(s)));
+                wv_atomic_add_lds(&S->count[c], 1);
+            }
+            wv_sync();
+            if (lane == 0) {
+                u32 max = kind == 0 ? ZSA_MaxLL : (kind == 1 ? ZSA_MaxOff : ZSA_MaxML);
+                while (!S->count[max]) max--;
+                u32 mostFrequent = 0;
+                for (u32 s = 0; s <= max; s++) if (S->count[s] > mostFrequent) mostFrequent = S->count[s];
+                u32* const rm = kind == 0 ? &S->nextLL : (kind == 1 ? &S->nextOF : &S->nextML);
+                int const defaultAllowed = kind == 1 ? (max <= ZSA_DefaultMaxOff) : 1;
+                u32 const dlog = kind == 1 ? ZSA_OF_DEFAULTNORMLOG : 6;
+                u32 const type = zsa_selectEncodingType(rm, mostFrequent, nbSeq, dlog, defaultAllowed);
+                u32 const lastCode = kind == 0 ? zsa_LLcode(zsa_seq_ll(lastSeq)) : (kind == 1 ? zsa_highbit32(zsa_seq_of(lastSeq)) : zsa_MLcode(zsa_seq_ml(lastSeq)));
+                u32 const firstCode = kind == 0 ? zsa_LLcode(zsa_seq_ll(firstSeq)) : (kind == 1 ? zsa_highbit32(zsa_seq_of(firstSeq)) : zsa_MLcode(zsa_seq_ml(firstSeq)));
+                ZsaFseCT* const ct = kind == 0 ? &S->ll : (kind == 1 ? &S->of : &S->ml);
+                const ZsaFseCT* const dt = cd ? (kind == 0 ? &cd->ll : (kind == 1 ? &cd->of : &cd->ml)) : (const ZsaFseCT*)0;
+                u32 fail = 0;
+                u32 const cs = zsa_buildSeqCTable(S, op, ct, kind, type, S->count, max, lastCode, firstCode, nbSeq, dt, &fail);
+                if (fail) S->err = ZSA_GENERIC;
+                S->u[EU_s0 + kind] = type; S->u[EU_tmp] = cs;
+            }
+            wv_sync();
+            if (S->err) return 0;
+            types[kind] = S->u[EU_s0 + kind];
+            if (types[kind] == zsa_set_compressed) lastCountSize = S->u[EU_tmp];
+            op += S->u[EU_tmp];
+            wv_sync();
+        }
+        // zstd_compress_sequences.c:291-383 ZSTD_encodeSequences_body, lane 0
+        if (lane == 0) {
+            *seqHead = (u8)((types[0] << 6) + (types[1] << 4) + (types[2] << 2));
+            ZsaBitW w;
+            ZsaFseCState sML, sOF, sLL;
+            zsa_bw_init(w, op);
+            {   u64 const s = seq[nbSeq - 1];
+                u32 const ll = zsa_seq_ll(s), ml = zsa_seq_ml(s), of = zsa_seq_of(s);
+                u32 const llc = zsa_LLcode(ll), mlc = zsa_MLcode(ml), ofc = zsa_highbit32(of);
+                zsa_fse_initCState2(sML, S->ml.nextState, S->ml.dfs, S->ml.dnb, S->ml.tableLog, mlc);
+                zsa_fse_initCState2(sOF, S->of.nextState, S->of.dfs, S->of.dnb, S->of.tableLog, ofc);
+                zsa_fse_initCState2(sLL, S->ll.nextState, S->ll.dfs, S->ll.dnb, S->ll.tableLog, llc);
+                zsa_bw_add(w, ll, zsa_LL_bits(llc));
+                zsa_bw_add(w, ml, zsa_ML_bits(mlc));
+                zsa_bw_add(w, of, ofc);
+            }
+            for (u32 n = nbSeq - 2; n < nbSeq; n--) {
+                u64 const s = seq[n];
+                u32 const ll = zsa_seq_ll(s), ml = zsa_seq_ml(s), of = zsa_seq_of(s);
+                u32 const llc = zsa_LLcode(ll), mlc = zsa_MLcode(ml), ofc = zsa_highbit32(of);
+                zsa_fse_encodeSymbol(w, sOF, ofc);
+                zsa_fse_encodeSymbol(w, sML, mlc);
+                zsa_fse_encodeSymbol(w, sLL, llc);
+                zsa_bw_add(w, ll, zsa_LL_bits(llc));
+                zsa_bw_add(w, ml, zsa_ML_bits(mlc));
+                zsa_bw_add(w, of, ofc);
+            }
+            zsa_bw_add(w, sML.value, sML.stateLog);
+            zsa_bw_add(w, sOF.value, sOF.stateLog);
+            zsa_bw_add(w, sLL.value, sLL.stateLog);
+            S->u[EU_tmp] = zsa_bw_close(w);
+        }
+        wv_sync();
+        u32 const bitstreamSize = S->u[EU_tmp];
+        op += bitstreamSize;
+        wv_sync();
+        if (lastCountSize && (lastCountSize + bitstreamSize) < 4) return 0;   // zstd_compress.c:2938-2944
+    }
+    {   u32 const cSize = (u32)(op - dst);
+        u32 const maxCSize = srcSize - ((srcSize >> 6) + 2);
+        if (cSize >= maxCSize) return 0;
+        return cSize;
+    }
+}
+
+// gather the literal runs named by the recorded sequences into `lit` (all lanes), ZSTD_storeSeq's copy
+// (zstd_compress_internal.h:675-687) + ZSTD_storeLastLiterals (zstd_compress.c:3065-3070)
+ZSA_DEV void zsa_gatherLiterals(ZsaEncShared* S, const u64* seq, u32 nbSeq, const u8* src, u32 srcSize, u32 lastLL, u8* lit, int lane)
+{
+    u32 litPos = 0, srcPos = 0;
+    for (u32 base = 0; base < nbSeq; base += ZSA_WAVE) {
+        u32 const n = (nbSeq - base) < ZSA_WAVE ? (nbSeq - base) : ZSA_WAVE;
+        u64 const s = (u32)lane < n ? seq[base + lane] : 0;
+        u32 const ll = (u32)lane < n ? zsa_seq_ll(s) : 0;
+        u32 const tot = (u32)lane < n ? ll + zsa_seq_ml(s) + ZSA_MINMATCH : 0;
+        u32 const litIncl = wv_scan_incl(ll), totIncl = wv_scan_incl(tot);
+        S->bLit[lane] = litIncl - ll; S->bSrc[lane] = totIncl - tot;
+        wv_sync();
+        u32 const totalLit = wv_shfl(litIncl, 63), totalSrc = wv_shfl(totIncl, 63);
+        for (u32 t = (u32)lane; t < totalLit; t += ZSA_WAVE) {
+            u32 lo = 0, hi = n - 1;
+            while (lo < hi) { u32 const mid = (lo + hi + 1) >> 1; if (S->bLit[mid] <= t) lo = mid; else hi = mid - 1; }
+            lit[litPos + t] = src[srcPos + S->bSrc[lo] + (t - S->bLit[lo])];
+        }
+        litPos += totalLit; srcPos += totalSrc;
+        wv_sync();
+    }
+    for (u32 t = (u32)lane; t < lastLL; t += ZSA_WAVE) lit[litPos + t] = src[srcSize - lastLL + t];
+}
+
+// ------------------------------------------------------------------ the frame (zstd_compress.c:4392-4632, 5107-5144)
+// hashTable: LDS, (1 << P.hlog) entries.  scratch: seq (u64 x (blockSizeMax/4 + 8)), lit (128 KiB + 64), tmp (lit-sized x 1.5 + 128).
+// Returns bytes written or (u64)-error (uniform).
+struct ZsaEncScratch { u64* seq; u8* lit; u8* tmp; };
+
+ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams& P, const u8* src, u64 srcSize64,
+                             u8* dst, u64 dstCapacity, const ZsaEncScratch& W, const ZsaCDictDev* cd)
+{
+    int const lane = wv_lane();
+    if (srcSize64 > 0xE0000000ull) return ZSA_ERR(ZSA_srcSize_wrong);
+    u32 const srcSize = (u32)srcSize64;
+    {   // capacity contract of this path: every reference call site passes ZSTD_compressBound(srcSize) (zstd.go:96-101)
+        u64 const bound = (u64)srcSize + (srcSize >> 8) + ((srcSize < (128u << 10)) ? (((128u << 10) - srcSize) >> 11) : 0);
+        if (dstCapacity < bound || dstCapacity < 18) return ZSA_ERR(ZSA_dstSize_tooSmall);
+    }
+    // frame header, zstd_compress.c:4474-4520
+    u32 pos = 0;
+    u32 const dictID = cd ? cd->dictID : 0;
+    {
+        u32 const dictIDSizeCode = (dictID > 0) + (dictID >= 256) + (dictID >= 65536);
+        u32 const singleSegment = ((u64)1 << P.wlog) >= srcSize;
+        u32 const fcsCode = (srcSize >= 256) + (srcSize >= 65536 + 256);
+        pos = 5 + !singleSegment + (dictIDSizeCode == 3 ? 4 : dictIDSizeCode) + (fcsCode == 0 ? singleSegment : (1u << fcsCode));
+        if (lane == 0) {
+            u32 q = 4;
+            zsa_st32(dst, ZSA_MAGIC);
+            dst[q++] = (u8)(dictIDSizeCode + (singleSegment << 5) + (fcsCode << 6));
+            if (!singleSegment) dst[q++] = (u8)((P.wlog - ZSA_WLOG_ABSMIN) << 3);
+            if (dictIDSizeCode == 1) { dst[q++] = (u8)dictID; }
+            else if (dictIDSizeCode == 2) { zsa_st16(dst + q, dictID); q += 2; }
+            else if (dictIDSizeCode == 3) { zsa_st32(dst + q, dictID); q += 4; }
+            if (fcsCode == 0) { if (singleSegment) dst[q++] = (u8)srcSize; }
+            else if (fcsCode == 1) { zsa_st16(dst + q, srcSize - 256); q += 2; }
+            else { zsa_st32(dst + q, srcSize); q += 4; }
+        }
+    }
+    u8* op = dst + pos;
+    if (srcSize == 0) {   // zstd_compress.c:5125-5132
+        if (lane == 0) zsa_st24(op, 1);
+        wv_sync();
+        return pos + 3;
+    }
+    // per-frame state (zstd_compress.c:2045-2225, 1863-1872)
+    for (u32 i = (u32)lane; i < (1u << P.hlog); i += ZSA_WAVE) hashTable[i] = 0;
+    for (u32 i = (u32)lane; i < 256; i += ZSA_WAVE) { S->hufPrev.nbBits[i] = 0; S->hufPrev.val[i] = 0; }
+    if (lane == 0) {
+        S->prevRep[0] = 1; S->prevRep[1] = 4; S->prevRep[2] = 8;
+        S->prevHufRepeat = zsa_rep_none; S->prevLL = S->prevOF = S->prevML = zsa_rep_none;
+        S->err = 0;
+    }
+    wv_sync();
+    u32 blockSize;
+    {   u64 const ws0 = ((u64)1 << P.wlog) < srcSize ? ((u64)1 << P.wlog) : srcSize;
+        blockSize = ws0 < ZSA_BLOCKSIZE_MAX ? (u32)ws0 : ZSA_BLOCKSIZE_MAX;
+    }
+    int const literalsDisabled = P.tlen > 0;
+    u32 const maxDist = 1u << P.wlog;
+    const u8* const base = src - 2;       // first byte of the frame has index 2 (zstd_compress_internal.h:211, 1232-1285)
+    u32 dictLimit = 2;
+    u32 remaining = srcSize;
+    const u8* ip = src;
+    int isFirstBlock = 1;
+    while (remaining) {
+        u32 const lastBlock = (blockSize >= remaining);
+        if (remaining < blockSize) blockSize = remaining;
+        {   // ZSTD_window_enforceMaxDist (zstd_compress_internal.h:1153-1190), no dictionary
+            u32 const blockStartIdx = (u32)(ip - base);
+            if (blockStartIdx > maxDist) { u32 const nl = blockStartIdx - maxDist; if (dictLimit < nl) dictLimit = nl; }
+        }
+        u32 cSize = 0;
+        if (blockSize >= 7) {   // zstd_compress.c:3156
+            if (lane == 0) {
+                u32 rep[3] = { S->prevRep[0], S->prevRep[1], S->prevRep[2] };
+                u32 lastLL = 0;
+                u32 const nbSeq = zsa_parse_fast(hashTable, P, base, dictLimit, ip, blockSize, rep, W.seq, &lastLL);
+                S->nextRep[0] = rep[0]; S->nextRep[1] = rep[1]; S->nextRep[2] = rep[2];
+                S->u[EU_nbSeq] = nbSeq; S->u[EU_lastLL] = lastLL;
+            }
+            wv_sync();
+            u32 const nbSeq = S->u[EU_nbSeq], lastLL = S->u[EU_lastLL];
+            // literal bytes = block bytes not covered by matches
+            u32 litSize;
+            {   u32 m = 0;
+                for (u32 i = (u32)lane; i < nbSeq; i += ZSA_WAVE) m += zsa_seq_ml(W.seq[i]) + ZSA_MINMATCH;
+                litSize = blockSize - wv_reduce_add(m);
+            }
+            zsa_gatherLiterals(S, W.seq, nbSeq, ip, blockSize, lastLL, W.lit, lane);
+            wv_sync();
+            cSize = zsa_entropyCompress(S, W.seq, nbSeq, W.lit, litSize, op + 3, blockSize, W.tmp, literalsDisabled, cd, lane);
+            if (S->err) return ZSA_ERR(S->err);
+            if (!isFirstBlock && cSize < 25) {   // zstd_compress.c:4258-4269 (ZSTD_isRLE :3413-3433)
+                u32 diff = 0;
+                u8 const b0 = ip[0];
+                for (u32 i = (u32)lane; i < blockSize; i += ZSA_WAVE) diff |= (ip[i] != b0);
+                if (!wv_ballot(diff != 0)) { cSize = 1; if (lane == 0) op[3] = b0; }
+            }
+        }
+        wv_sync();
+        if (cSize > 1 && lane == 0) {   // zstd_compress.c:4272-4274 confirm repcodes + entropy tables
+            S->prevRep[0] = S->nextRep[0]; S->prevRep[1] = S->nextRep[1]; S->prevRep[2] = S->nextRep[2];
+            S->prevHufRepeat = S->nextHufRepeat; S->prevLL = S->nextLL; S->prevOF = S->nextOF; S->prevML = S->nextML;
+        }
+        if (cSize > 1) for (u32 i = (u32)lane; i < 256; i += ZSA_WAVE) { S->hufPrev.nbBits[i] = S->hufNext.nbBits[i]; S->hufPrev.val[i] = S->hufNext.val[i]; }
+        wv_sync();
+        if (lane == 0 && S->prevOF == zsa_rep_valid) S->prevOF = zsa_rep_check;   // :4279-4280
+        if (cSize == 0) {   // ZSTD_noCompressBlock, zstd_compress_internal.h:569-579
+            if (lane == 0) zsa_st24(op, lastBlock + ((u32)zsa_bt_raw << 1) + (blockSize << 3));
+            for (u32 i = (u32)lane; i < blockSize; i += ZSA_WAVE) op[3 + i] = ip[i];
+            cSize = 3 + blockSize;
+        } else {
+            if (lane == 0) zsa_st24(op, cSize == 1 ? lastBlock + ((u32)zsa_bt_rle << 1) + (blockSize << 3)
+                                                   : lastBlock + ((u32)zsa_bt_compressed << 1) + (cSize << 3));
+            cSize += 3;
+        }
+        ip += blockSize; remaining -= blockSize;
+        op += cSize;
+        isFirstBlock = 0;
+        wv_sync();
+    }
+    return (u64)(op - dst);
+}

@@ -1,0 +1,386 @@
+// zsa_lib.hip -- libzstd_amd.so: kernels + the C ABI declared in include/zstd_amd.h.
+// MI355X (gfx950) only.  No CPU data path: every entry point that moves frame data launches the kernels below.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include <vector>
+#include "zsa_common.h"
+#include "zsa_params.h"
+#include "zsa_decode.h"
+#include "zsa_encode.h"
+#include "../../include/zstd_amd.h"
+
+// ------------------------------------------------------------------------------------------------ kernels
+// One 64-lane workgroup per frame at a time; workgroups pull frame indices from a device counter, so a launch
+// of (CUs x resident workgroups) keeps every CU busy however frame costs vary.
+#define ZSA_SEQ_CAP   (ZSA_BLOCKSIZE_MAX / 4 + 64)          // packed sequences per block (zstd_compress.c:1642-1645)
+#define ZSA_LIT_CAP   (ZSA_BLOCKSIZE_MAX + 128)
+#define ZSA_TMP_CAP   (ZSA_BLOCKSIZE_MAX * 3 / 2 + 512)
+#define ZSA_ENC_SCRATCH_BYTES ((size_t)ZSA_SEQ_CAP * 8 + ZSA_LIT_CAP + ZSA_TMP_CAP)
+#define ZSA_DEC_SCRATCH_BYTES ((size_t)ZSA_LIT_CAP)
+
+struct ZsaLaunchDict { const ZsaCDictDev* cd; const ZsaDDictDev* dd; };
+
+__global__ void __launch_bounds__(64, 2)
+zsa_k_decompress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
+                 u32* __restrict__ counter, u8* __restrict__ scratch, const ZsaDDictDev* dd)
+{
+    __shared__ ZsaDecShared S;
+    __shared__ u32 nextFrame;
+    u8* const litBuf = scratch + (size_t)blockIdx.x * ZSA_DEC_SCRATCH_BYTES;
+    for (;;) {
+        if (threadIdx.x == 0) nextFrame = atomicAdd(counter, 1u);
+        __syncthreads();
+        u32 const f = nextFrame;
+        __syncthreads();
+        if (f >= nFrames) break;
+        ZsaFrameDesc const d = frames[f];
+        u64 const r = zsa_decode_frames(&S, d.src, d.srcSize, d.dst, d.dstCapacity, litBuf, dd);
+        if (threadIdx.x == 0) results[f] = r;
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(64, 2)
+zsa_k_compress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
+               u32* __restrict__ counter, u8* __restrict__ scratch, int level, const ZsaCDictDev* cd)
+{
+    extern __shared__ __align__(16) u32 zsa_hashTable[];
+    __shared__ ZsaEncShared S;
+    __shared__ u32 nextFrame;
+    u8* const wg = scratch + (size_t)blockIdx.x * ZSA_ENC_SCRATCH_BYTES;
+    ZsaEncScratch W;
+    W.seq = (u64*)wg; W.lit = wg + (size_t)ZSA_SEQ_CAP * 8; W.tmp = W.lit + ZSA_LIT_CAP;
+    for (;;) {
+        if (threadIdx.x == 0) nextFrame = atomicAdd(counter, 1u);
+        __syncthreads();
+        u32 const f = nextFrame;
+        __syncthreads();
+        if (f >= nFrames) break;
+        ZsaFrameDesc const d = frames[f];
+        ZsaCParams cp;
+        u64 r;
+        if (zsa_resolveCParams(&cp, level, d.srcSize, 0, zsa_cpm_noAttachDict) || cp.strat != 1) r = ZSA_ERR(ZSA_parameter_unsupported);
+        else {
+            ZsaEncParams P; P.wlog = cp.wlog; P.hlog = cp.hlog; P.mml = cp.mml; P.tlen = cp.tlen;
+            r = zsa_encode_frame(&S, zsa_hashTable, P, d.src, d.srcSize, d.dst, d.dstCapacity, W, cd);
+        }
+        if (threadIdx.x == 0) results[f] = r;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "libzstd_amd: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return ZSA_ERR(ZSA_GENERIC); } } while (0)
+
+static const size_t kErrMemory = (size_t)ZSA_ERR(ZSA_memory_allocation);
+static const size_t kErrGeneric = (size_t)ZSA_ERR(ZSA_GENERIC);
+
+struct zsa_batch_s {
+    size_t maxFrames, nFrames;
+    ZsaFrameDesc* h_frames;      // pinned
+    ZsaFrameDesc* d_frames;
+    u64* d_results; u64* h_results;   // h_results pinned
+    u32* d_counter;
+    u8*  d_scratch; size_t scratchBytes;
+    int  numCU;
+    u64  maxSrcSize;
+    unsigned lastWG, lastLDS;
+};
+
+extern "C" int zsa_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+extern "C" const char* zsa_version(void) { return "zstd_amd 0.1 (format-compatible with libzstd 1.5.5, gfx950)"; }
+
+extern "C" size_t zsa_compressBound(size_t srcSize)
+{
+    if (srcSize >= 0xFF00FF00FF00FF00ULL) return (size_t)ZSA_ERR(ZSA_srcSize_wrong);
+    return (size_t)zsa_bound(srcSize);
+}
+extern "C" unsigned zsa_isError(size_t code) { return code > (size_t)ZSA_ERR(ZSA_maxCode); }
+extern "C" const char* zsa_getErrorName(size_t code)
+{   // error_private.c:16-66: the strings are part of the boundary (errors.go:29-34 string-matches one of them)
+    if (!zsa_isError(code)) return "No error detected";
+    switch ((u32)((size_t)0 - code)) {
+    case ZSA_GENERIC: return "Error (generic)";
+    case ZSA_prefix_unknown: return "Unknown frame descriptor";
+    case ZSA_version_unsupported: return "Version not supported";
+    case ZSA_frameParameter_unsupported: return "Unsupported frame parameter";
+    case ZSA_frameParameter_windowTooLarge: return "Frame requires too much memory for decoding";
+    case ZSA_corruption_detected: return "Data corruption detected";
+    case ZSA_checksum_wrong: return "Restored data doesn't match checksum";
+    case ZSA_literals_headerWrong: return "Header of Literals' block doesn't respect format specification";
+    case ZSA_parameter_unsupported: return "Unsupported parameter";
+    case ZSA_parameter_combination_unsupported: return "Unsupported combination of parameters";
+    case ZSA_parameter_outOfBound: return "Parameter is out of bound";
+    case ZSA_init_missing: return "Context should be init first";
+    case ZSA_memory_allocation: return "Allocation error : not enough memory";
+    case ZSA_workSpace_tooSmall: return "workSpace buffer is not large enough";
+    case ZSA_stage_wrong: return "Operation not authorized at current processing stage";
+    case ZSA_tableLog_tooLarge: return "tableLog requires too much memory : unsupported";
+    case ZSA_maxSymbolValue_tooLarge: return "Unsupported max Symbol Value : too large";
+    case ZSA_maxSymbolValue_tooSmall: return "Specified maxSymbolValue is too small";
+    case ZSA_stabilityCondition_notRespected: return "pledged buffer stability condition is not respected";
+    case ZSA_dictionary_corrupted: return "Dictionary is corrupted";
+    case ZSA_dictionary_wrong: return "Dictionary mismatch";
+    case ZSA_dictionaryCreation_failed: return "Cannot create Dictionary from provided samples";
+    case ZSA_dstSize_tooSmall: return "Destination buffer is too small";
+    case ZSA_srcSize_wrong: return "Src size is incorrect";
+    case ZSA_dstBuffer_null: return "Operation on NULL destination buffer";
+    case ZSA_noForwardProgress_destFull: return "Operation made no progress over multiple calls, due to output buffer being full";
+    case ZSA_noForwardProgress_inputEmpty: return "Operation made no progress over multiple calls, due to input being empty";
+    case ZSA_frameIndex_tooLarge: return "Frame index is too large";
+    case ZSA_seekableIO: return "An I/O error occurred when reading/seeking";
+    case ZSA_dstBuffer_wrong: return "Destination buffer is wrong";
+    case ZSA_srcBuffer_wrong: return "Source buffer is wrong";
+    case ZSA_sequenceProducer_failed: return "Block-level external sequence producer returned an error code";
+    case ZSA_externalSequences_invalid: return "External sequences are not valid";
+    default: return "Unspecified error code";
+    }
+}
+
+extern "C" int zsa_getCParams(int level, unsigned long long srcSize, size_t dictSize, int mode, unsigned out[7])
+{
+    ZsaCParams cp;
+    if (zsa_resolveCParams(&cp, level, srcSize, dictSize, mode)) return 1;
+    out[0] = cp.wlog; out[1] = cp.clog; out[2] = cp.hlog; out[3] = cp.slog; out[4] = cp.mml; out[5] = cp.tlen; out[6] = cp.strat;
+    return 0;
+}
+
+// zstd_decompress.c:445-581: frame-header peek done where the bytes are (host memory); no frame data is decoded here
+extern "C" unsigned long long zsa_getFrameContentSize(const void* srcv, size_t srcSize)
+{
+    const u8* src = (const u8*)srcv;
+    unsigned long long const ERRV = (unsigned long long)0 - 2, UNKNOWN = (unsigned long long)0 - 1;
+    if (srcSize < 5 || src == NULL) return ERRV;
+    u32 magic; memcpy(&magic, src, 4);
+    if (magic != ZSA_MAGIC) {
+        if ((magic & ZSA_MAGIC_SKIP_MASK) == ZSA_MAGIC_SKIP_START) return srcSize < 8 ? ERRV : 0;
+        return ERRV;   // includes legacy (v0.x) magics: outside this engine
+    }
+    u8 const fhd = src[4];
+    u32 const dictIDCode = fhd & 3, singleSegment = (fhd >> 5) & 1, fcsID = fhd >> 6;
+    u32 const didSize = dictIDCode == 3 ? 4 : dictIDCode;
+    u32 const fcsSize = fcsID == 0 ? singleSegment : (1u << fcsID);
+    size_t const fhs = 5 + !singleSegment + didSize + fcsSize;
+    if (srcSize < fhs) return ERRV;
+    if (fhd & 0x08) return ERRV;
+    size_t pos = 5;
+    if (!singleSegment) { u8 const wl = src[pos++]; if ((u32)(wl >> 3) + ZSA_WLOG_ABSMIN > ZSA_WLOG_MAX) return ERRV; }
+    pos += didSize;
+    switch (fcsID) {
+    case 0: return singleSegment ? src[pos] : UNKNOWN;
+    case 1: { u16 v; memcpy(&v, src + pos, 2); return (unsigned long long)v + 256; }
+    case 2: { u32 v; memcpy(&v, src + pos, 4); return v; }
+    default: { u64 v; memcpy(&v, src + pos, 8); return v; }
+    }
+}
+
+// ---- batch object
+extern "C" void zsa_batch_free(zsa_batch* b)
+{
+    if (!b) return;
+    if (b->h_frames) (void)hipHostFree(b->h_frames);
+    if (b->h_results) (void)hipHostFree(b->h_results);
+    if (b->d_frames) (void)hipFree(b->d_frames);
+    if (b->d_results) (void)hipFree(b->d_results);
+    if (b->d_counter) (void)hipFree(b->d_counter);
+    if (b->d_scratch) (void)hipFree(b->d_scratch);
+    free(b);
+}
+#define ZSA_MAX_WG_PER_CU 8
+extern "C" zsa_batch* zsa_batch_create(size_t maxFrames)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { fprintf(stderr, "libzstd_amd: no usable HIP device\n"); return NULL; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return NULL;
+    zsa_batch* b = (zsa_batch*)calloc(1, sizeof(zsa_batch));
+    if (!b) return NULL;
+    if (maxFrames == 0) maxFrames = 1;
+    b->maxFrames = maxFrames;
+    b->numCU = prop.multiProcessorCount;
+    size_t const maxWG = (size_t)b->numCU * ZSA_MAX_WG_PER_CU;
+    size_t const wgs = maxFrames < maxWG ? maxFrames : maxWG;
+    b->scratchBytes = wgs * (ZSA_ENC_SCRATCH_BYTES > ZSA_DEC_SCRATCH_BYTES ? ZSA_ENC_SCRATCH_BYTES : ZSA_DEC_SCRATCH_BYTES);
+    bool ok = hipHostMalloc((void**)&b->h_frames, maxFrames * sizeof(ZsaFrameDesc), hipHostMallocDefault) == hipSuccess
+           && hipHostMalloc((void**)&b->h_results, maxFrames * sizeof(u64), hipHostMallocDefault) == hipSuccess
+           && hipMalloc((void**)&b->d_frames, maxFrames * sizeof(ZsaFrameDesc)) == hipSuccess
+           && hipMalloc((void**)&b->d_results, maxFrames * sizeof(u64)) == hipSuccess
+           && hipMalloc((void**)&b->d_counter, 256) == hipSuccess
+           && hipMalloc((void**)&b->d_scratch, b->scratchBytes) == hipSuccess;
+    if (!ok) { fprintf(stderr, "libzstd_amd: device allocation failed (%zu frames)\n", maxFrames); zsa_batch_free(b); return NULL; }
+    return b;
+}
+extern "C" size_t zsa_batch_set_frame(zsa_batch* b, size_t i, const void* d_src, size_t srcSize, void* d_dst, size_t dstCapacity)
+{
+    if (!b || i >= b->maxFrames) return (size_t)ZSA_ERR(ZSA_parameter_outOfBound);
+    b->h_frames[i].src = (const u8*)d_src; b->h_frames[i].dst = (u8*)d_dst;
+    b->h_frames[i].srcSize = srcSize; b->h_frames[i].dstCapacity = dstCapacity;
+    return 0;
+}
+extern "C" size_t zsa_batch_upload(zsa_batch* b, size_t nFrames, void* stream)
+{
+    if (!b || nFrames > b->maxFrames) return (size_t)ZSA_ERR(ZSA_parameter_outOfBound);
+    b->nFrames = nFrames;
+    u64 m = 0;
+    for (size_t i = 0; i < nFrames; i++) if (b->h_frames[i].srcSize > m) m = b->h_frames[i].srcSize;
+    b->maxSrcSize = m;
+    if (nFrames) HIPCHK(hipMemcpyAsync(b->d_frames, b->h_frames, nFrames * sizeof(ZsaFrameDesc), hipMemcpyHostToDevice, (hipStream_t)stream));
+    return 0;
+}
+static unsigned zsa_grid(const zsa_batch* b, size_t ldsPerWG)
+{
+    size_t perCU = (160 * 1024) / (ldsPerWG ? ldsPerWG : 1);
+    if (perCU > ZSA_MAX_WG_PER_CU) perCU = ZSA_MAX_WG_PER_CU;
+    if (perCU < 1) perCU = 1;
+    size_t g = (size_t)b->numCU * perCU;
+    if (g > b->nFrames) g = b->nFrames;
+    return (unsigned)(g ? g : 1);
+}
+extern "C" size_t zsa_compress_enqueue(zsa_batch* b, int level, const zsa_CDict* cdict, void* stream)
+{
+    if (!b) return kErrGeneric;
+    if (b->nFrames == 0) return 0;
+    if (cdict) return (size_t)ZSA_ERR(ZSA_parameter_unsupported);
+    // LDS: hash table of the largest frame in the batch (hashLog depends on the size class)
+    u32 maxHlog = 6;
+    {   // hashLog is not monotone in srcSize across size classes: take the max over the classes present
+        for (size_t i = 0; i < b->nFrames; i++) {
+            ZsaCParams cp;
+            if (zsa_resolveCParams(&cp, level, b->h_frames[i].srcSize, 0, zsa_cpm_noAttachDict) == 0 && cp.strat == 1 && cp.hlog > maxHlog) maxHlog = cp.hlog;
+        }
+    }
+    if (maxHlog > 15) return (size_t)ZSA_ERR(ZSA_parameter_unsupported);
+    size_t const dynLds = (size_t)4 << maxHlog;
+    size_t const ldsPerWG = dynLds + sizeof(ZsaEncShared) + 64;
+    static std::once_flag once;
+    std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)zsa_k_compress, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); });
+    unsigned const grid = zsa_grid(b, ldsPerWG);
+    HIPCHK(hipMemsetAsync(b->d_counter, 0, 256, (hipStream_t)stream));
+    hipLaunchKernelGGL(zsa_k_compress, dim3(grid), dim3(64), dynLds, (hipStream_t)stream,
+                       b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter, b->d_scratch, level, (const ZsaCDictDev*)nullptr);
+    HIPCHK(hipGetLastError());
+    b->lastWG = grid; b->lastLDS = (unsigned)ldsPerWG;
+    return 0;
+}
+extern "C" size_t zsa_decompress_enqueue(zsa_batch* b, const zsa_DDict* ddict, void* stream)
+{
+    if (!b) return kErrGeneric;
+    if (b->nFrames == 0) return 0;
+    if (ddict) return (size_t)ZSA_ERR(ZSA_parameter_unsupported);
+    size_t const ldsPerWG = sizeof(ZsaDecShared) + 64;
+    unsigned const grid = zsa_grid(b, ldsPerWG);
+    HIPCHK(hipMemsetAsync(b->d_counter, 0, 256, (hipStream_t)stream));
+    hipLaunchKernelGGL(zsa_k_decompress, dim3(grid), dim3(64), 0, (hipStream_t)stream,
+                       b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter, b->d_scratch, (const ZsaDDictDev*)nullptr);
+    HIPCHK(hipGetLastError());
+    b->lastWG = grid; b->lastLDS = (unsigned)ldsPerWG;
+    return 0;
+}
+extern "C" size_t zsa_batch_results(zsa_batch* b, size_t* outSize, void* stream)
+{
+    if (!b) return kErrGeneric;
+    if (b->nFrames) HIPCHK(hipMemcpyAsync(b->h_results, b->d_results, b->nFrames * sizeof(u64), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    for (size_t i = 0; i < b->nFrames; i++) outSize[i] = (size_t)b->h_results[i];
+    return 0;
+}
+extern "C" const uint64_t* zsa_batch_device_results(const zsa_batch* b) { return b ? b->d_results : NULL; }
+extern "C" void zsa_batch_last_launch(const zsa_batch* b, unsigned* wg, unsigned* lds) { if (b) { if (wg) *wg = b->lastWG; if (lds) *lds = b->lastLDS; } }
+
+// ---- host-memory batches: stage through pinned buffers, run the device batch, copy results back
+struct ZsaStage {
+    u8 *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr;
+    size_t inCap = 0, outCap = 0;
+    zsa_batch* batch = nullptr;
+    hipStream_t stream = nullptr;
+    int device = -1;
+    ~ZsaStage() { /* process teardown: leave device memory to the runtime */ }
+};
+static thread_local ZsaStage t_stage;
+
+static size_t zsa_stage_reserve(ZsaStage& st, size_t inBytes, size_t outBytes, size_t nFrames)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { fprintf(stderr, "libzstd_amd: no usable HIP device -- this library has no CPU path\n"); return kErrGeneric; }
+    if (st.device != dev) {   // first use on this thread/device
+        if (st.stream == nullptr) HIPCHK(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
+        st.device = dev;
+    }
+    if (inBytes > st.inCap) {
+        if (st.h_in) { (void)hipHostFree(st.h_in); (void)hipFree(st.d_in); st.h_in = st.d_in = nullptr; st.inCap = 0; }
+        size_t const cap = inBytes + (inBytes >> 2) + 4096;
+        if (hipHostMalloc((void**)&st.h_in, cap, hipHostMallocDefault) != hipSuccess || hipMalloc((void**)&st.d_in, cap) != hipSuccess) return kErrMemory;
+        st.inCap = cap;
+    }
+    if (outBytes > st.outCap) {
+        if (st.h_out) { (void)hipHostFree(st.h_out); (void)hipFree(st.d_out); st.h_out = st.d_out = nullptr; st.outCap = 0; }
+        size_t const cap = outBytes + (outBytes >> 2) + 4096;
+        if (hipHostMalloc((void**)&st.h_out, cap, hipHostMallocDefault) != hipSuccess || hipMalloc((void**)&st.d_out, cap) != hipSuccess) return kErrMemory;
+        st.outCap = cap;
+    }
+    if (!st.batch || st.batch->maxFrames < nFrames) {
+        if (st.batch) zsa_batch_free(st.batch);
+        size_t cap = nFrames < 64 ? 64 : nFrames + (nFrames >> 2);
+        st.batch = zsa_batch_create(cap);
+        if (!st.batch) return kErrMemory;
+    }
+    return 0;
+}
+
+static size_t zsa_run_host_batch(bool compress, const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCapacity,
+                                 size_t* outSize, size_t n, int level, const zsa_CDict* cd, const zsa_DDict* dd)
+{
+    if (n == 0) return 0;
+    ZsaStage& st = t_stage;
+    // layout: inputs and outputs packed back to back, 16-byte aligned, with 32 bytes of slack after each input
+    std::vector<size_t> inOff(n), outOff(n);
+    size_t inBytes = 0, outBytes = 0;
+    for (size_t i = 0; i < n; i++) {
+        inOff[i] = inBytes; inBytes += (srcSize[i] + 32 + 15) & ~(size_t)15;
+        outOff[i] = outBytes; outBytes += (dstCapacity[i] + 15) & ~(size_t)15;
+    }
+    { size_t const e = zsa_stage_reserve(st, inBytes, outBytes, n); if (e) return e; }
+    for (size_t i = 0; i < n; i++) {
+        if (srcSize[i]) memcpy(st.h_in + inOff[i], src[i], srcSize[i]);
+        zsa_batch_set_frame(st.batch, i, st.d_in + inOff[i], srcSize[i], st.d_out + outOff[i], dstCapacity[i]);
+    }
+    HIPCHK(hipMemcpyAsync(st.d_in, st.h_in, inBytes, hipMemcpyHostToDevice, st.stream));
+    { size_t const e = zsa_batch_upload(st.batch, n, st.stream); if (e) return e; }
+    { size_t const e = compress ? zsa_compress_enqueue(st.batch, level, cd, st.stream) : zsa_decompress_enqueue(st.batch, dd, st.stream); if (e) return e; }
+    { size_t const e = zsa_batch_results(st.batch, outSize, st.stream); if (e) return e; }
+    // copy back only what was produced
+    size_t lo = (size_t)-1, hi = 0;
+    for (size_t i = 0; i < n; i++) if (!zsa_isError(outSize[i]) && outSize[i]) { if (outOff[i] < lo) lo = outOff[i]; if (outOff[i] + outSize[i] > hi) hi = outOff[i] + outSize[i]; }
+    if (hi > lo) {
+        HIPCHK(hipMemcpyAsync(st.h_out + lo, st.d_out + lo, hi - lo, hipMemcpyDeviceToHost, st.stream));
+        HIPCHK(hipStreamSynchronize(st.stream));
+        for (size_t i = 0; i < n; i++) if (!zsa_isError(outSize[i]) && outSize[i]) memcpy(dst[i], st.h_out + outOff[i], outSize[i]);
+    }
+    return 0;
+}
+
+extern "C" size_t zsa_compress_batch(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCapacity,
+                                     size_t* outSize, size_t n, int level, const zsa_CDict* cdict)
+{ return zsa_run_host_batch(true, src, srcSize, dst, dstCapacity, outSize, n, level, cdict, nullptr); }
+extern "C" size_t zsa_decompress_batch(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCapacity,
+                                       size_t* outSize, size_t n, const zsa_DDict* ddict)
+{ return zsa_run_host_batch(false, src, srcSize, dst, dstCapacity, outSize, n, 0, nullptr, ddict); }
+
+extern "C" size_t zsa_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level)
+{
+    size_t out = 0;
+    size_t const e = zsa_compress_batch(&src, &srcSize, &dst, &dstCapacity, &out, 1, level, nullptr);
+    return e ? e : out;
+}
+extern "C" size_t zsa_decompress(void* dst, size_t dstCapacity, const void* src, size_t srcSize)
+{
+    size_t out = 0;
+    size_t const e = zsa_decompress_batch(&src, &srcSize, &dst, &dstCapacity, &out, 1, nullptr);
+    return e ? e : out;
+}
+
+// ---- dictionaries (device-resident digests) -- see zsa_dict.inc
+#include "zsa_dict.inc"

@@ -1,0 +1,71 @@
+// zsa_params.h -- compression-parameter resolution, usable from host and device code.
+// Restates ZSTD_getCParams_internal + ZSTD_adjustCParams_internal (zstd_compress.c:6935-6983, 1427-1555) for the
+// clevels.h rows whose strategy this engine implements (ZSTD_fast).
+#pragma once
+#include "zsa_common.h"
+
+struct ZsaCParams { u32 wlog, clog, hlog, slog, mml, tlen, strat; };
+enum { zsa_cpm_noAttachDict = 0, zsa_cpm_attachDict = 1, zsa_cpm_createCDict = 2 };
+#define ZSA_SIZE_UNKNOWN (~(u64)0)
+
+ZSA_HD u32 zsa_hb32(u32 v) { return 31u - (u32)__builtin_clz(v); }
+
+ZSA_HD ZsaCParams zsa_levelRow(u32 tableID, u32 row)
+{   // clevels.h:26-131, rows {negative-level base, 1, 2, 3}
+    const u8 t[4][4][7] = {
+        { {19,12,13,1,6,1,1}, {19,13,14,1,7,0,1}, {20,15,16,1,6,0,1}, {21,16,17,1,5,0,2} },
+        { {18,12,13,1,5,1,1}, {18,13,14,1,6,0,1}, {18,14,14,1,5,0,2}, {18,16,16,1,4,0,2} },
+        { {17,12,12,1,5,1,1}, {17,12,13,1,6,0,1}, {17,13,15,1,5,0,1}, {17,15,16,2,5,0,2} },
+        { {14,12,13,1,5,1,1}, {14,14,15,1,5,0,1}, {14,14,15,1,4,0,1}, {14,14,15,2,4,0,2} } };
+    ZsaCParams c;
+    c.wlog = t[tableID][row][0]; c.clog = t[tableID][row][1]; c.hlog = t[tableID][row][2]; c.slog = t[tableID][row][3];
+    c.mml = t[tableID][row][4]; c.tlen = t[tableID][row][5]; c.strat = t[tableID][row][6];
+    return c;
+}
+// returns 0 ok, 1 level outside the table
+ZSA_HD int zsa_resolveCParams(ZsaCParams* out, int level, u64 srcSizeHint, u64 dictSize, int mode)
+{
+    u64 rSize;
+    {   u64 const ds = (mode == zsa_cpm_attachDict) ? 0 : dictSize;
+        int const unknown = srcSizeHint == ZSA_SIZE_UNKNOWN;
+        u64 const addedSize = unknown && ds > 0 ? 500 : 0;
+        rSize = unknown && ds == 0 ? ZSA_SIZE_UNKNOWN : srcSizeHint + ds + addedSize;
+    }
+    u32 const tableID = (rSize <= 256 * 1024) + (rSize <= 128 * 1024) + (rSize <= 16 * 1024);
+    u32 row;
+    if (level == 0) row = 3; else if (level < 0) row = 0; else if (level > 3) return 1; else row = (u32)level;
+    ZsaCParams cp = zsa_levelRow(tableID, row);
+    if (level < 0) { int const minLevel = -(1 << 17); int const cl = level < minLevel ? minLevel : level; cp.tlen = (u32)(-cl); }
+    // ZSTD_adjustCParams_internal
+    u64 srcSize = srcSizeHint;
+    if (mode == zsa_cpm_createCDict) { if (dictSize && srcSize == ZSA_SIZE_UNKNOWN) srcSize = 513; }
+    else if (mode == zsa_cpm_attachDict) dictSize = 0;
+    u64 const maxWindowResize = (u64)1 << (ZSA_WLOG_MAX - 1);
+    if (srcSize <= maxWindowResize && dictSize <= maxWindowResize) {
+        u32 const tSize = (u32)(srcSize + dictSize);
+        u32 const srcLog = (tSize < (1u << 6)) ? 6 : zsa_hb32(tSize - 1) + 1;
+        if (cp.wlog > srcLog) cp.wlog = srcLog;
+    }
+    if (srcSize != ZSA_SIZE_UNKNOWN) {
+        u32 dawLog = cp.wlog;   // ZSTD_dictAndWindowLog
+        if (dictSize) {
+            u64 const windowSize = (u64)1 << cp.wlog, dws = dictSize + windowSize;
+            if (windowSize >= dictSize + srcSize) dawLog = cp.wlog;
+            else if (dws >= ((u64)1 << ZSA_WLOG_MAX)) dawLog = ZSA_WLOG_MAX;
+            else dawLog = zsa_hb32((u32)dws - 1) + 1;
+        }
+        if (cp.hlog > dawLog + 1) cp.hlog = dawLog + 1;
+        if (cp.clog > dawLog) cp.clog -= (cp.clog - dawLog);
+    }
+    if (cp.wlog < ZSA_WLOG_ABSMIN) cp.wlog = ZSA_WLOG_ABSMIN;
+    if (mode == zsa_cpm_createCDict && (cp.strat == 1 || cp.strat == 2)) {
+        if (cp.hlog > 24) cp.hlog = 24;
+        if (cp.clog > 24) cp.clog = 24;
+    }
+    *out = cp;
+    return 0;
+}
+ZSA_HD u64 zsa_bound(u64 srcSize)
+{   // zstd.h ZSTD_COMPRESSBOUND
+    return srcSize + (srcSize >> 8) + ((srcSize < (128u << 10)) ? (((128u << 10) - srcSize) >> 11) : 0);
+}

@@ -1,0 +1,43 @@
+// zsa_wave_hip.h -- wave-level primitives for gfx950 (64-lane wavefronts).  The kernels are written against
+// this small vocabulary only, so that tests can also run the same kernel bodies on the CPU under a
+// lock-step lane emulator (tests/emu/zsa_wave_emu.h) to localise bugs before going to the GPU.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define ZSA_DEV    __device__ __forceinline__
+#define ZSA_DEVFN  __device__ __noinline__
+#define ZSA_HD     __host__ __device__ inline
+#define ZSA_SHARED __shared__
+#define ZSA_WAVE   64
+
+ZSA_DEV int wv_lane() { return (int)(threadIdx.x & 63u); }
+ZSA_DEV unsigned long long wv_ballot(bool p) { return __ballot(p); }
+ZSA_DEV unsigned wv_shfl(unsigned v, int srcLane) { return (unsigned)__shfl((int)v, srcLane, 64); }
+ZSA_DEV unsigned wv_shfl_up(unsigned v, int delta) { return (unsigned)__shfl_up((int)v, (unsigned)delta, 64); }
+ZSA_DEV unsigned wv_shfl_xor(unsigned v, int mask) { return (unsigned)__shfl_xor((int)v, mask, 64); }
+// Workgroup == one wave here: orders LDS and global accesses between the lanes of the wave.
+ZSA_DEV void wv_sync() { __syncthreads(); }
+ZSA_DEV unsigned wv_atomic_add_lds(unsigned* p, unsigned v) { return atomicAdd(p, v); }
+ZSA_DEV unsigned wv_atomic_or_lds(unsigned* p, unsigned v) { return atomicOr(p, v); }
+ZSA_DEV unsigned wv_atomic_add_global(unsigned* p, unsigned v) { return atomicAdd(p, v); }
+
+// inclusive prefix sum over the 64 lanes
+ZSA_DEV unsigned wv_scan_incl(unsigned v)
+{
+    const int lane = wv_lane();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { unsigned t = wv_shfl_up(v, d); if (lane >= d) v += t; }
+    return v;
+}
+ZSA_DEV unsigned wv_reduce_add(unsigned v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += wv_shfl_xor(v, d);
+    return v;
+}
+ZSA_DEV unsigned wv_reduce_max(unsigned v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { unsigned t = wv_shfl_xor(v, d); v = t > v ? t : v; }
+    return v;
+}
