@@ -71,6 +71,13 @@ zsa_batch* zsa_batch_create(size_t maxFrames);
 void       zsa_batch_free(zsa_batch* b);
 /* describe frame i: device pointers */
 size_t zsa_batch_set_frame(zsa_batch* b, size_t i, const void* d_src, size_t srcSize, void* d_dst, size_t dstCapacity);
+/* describe frames 0..nFrames-1 laid out at fixed strides: frame i reads d_src + i*srcStride (srcSizes[i] bytes, or
+ * srcStride bytes when srcSizes is NULL) and writes d_dst + i*dstStride (capacity dstCapacity each) */
+size_t zsa_batch_set_frames_strided(zsa_batch* b, size_t nFrames, const void* d_src, size_t srcStride, const size_t* srcSizes,
+                                    void* d_dst, size_t dstStride, size_t dstCapacity);
+/* on the device, without a host round trip: consumer frame i takes its srcSize from the result word of producer
+ * frame i (a failed producer frame yields srcSize 0).  Lets compress -> decompress chains stay on the GPU. */
+size_t zsa_batch_link_src_sizes(zsa_batch* consumer, const zsa_batch* producer, void* stream);
 /* upload the first nFrames descriptors (async on stream) */
 size_t zsa_batch_upload(zsa_batch* b, size_t nFrames, void* stream);
 /* launch; results stay on the device until zsa_batch_results */

@@ -1,0 +1,59 @@
+"""CPU tests that run the HIP kernel BODIES (zsa_decode.h / zsa_encode.h) under the lock-step lane emulator
+(tests/emu/).  A debugging aid that keeps kernel logic honest without a GPU; GPU parity itself is proven by the
+`-m gpu` tests through the C ABI."""
+import ctypes
+import os
+import random
+import subprocess
+
+import pytest
+
+from zstd_amd import corpus
+import zstd_amd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def emu():
+    d = os.path.join(ROOT, "tests", "emu")
+    subprocess.run(["make", "-s", "-C", d], check=True)
+    lib = ctypes.CDLL(os.path.join(d, "libzsa_emu.so"))
+    lib.emu_compress.restype = ctypes.c_size_t
+    lib.emu_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t] + [ctypes.c_uint] * 4
+    lib.emu_decompress.restype = ctypes.c_size_t
+    lib.emu_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    return lib
+
+
+def _inputs():
+    rnd = random.Random(99)
+    out = [b"", b"a", b"abcdefg", bytes(5000), rnd.randbytes(3000), b"ab" * 5000]
+    out += corpus.frames("log", 131072, 2, 42) + corpus.frames("json", 65536, 2, 1234) + corpus.frames("log", 262144, 1, 43)
+    out += corpus.frames("json", 1024, 8, 7) + corpus.frames("log", 12000, 2, 6)
+    out.append(rnd.randbytes(131072) + bytes(100000))
+    return out
+
+
+def test_emulated_kernels_match_oracle(emu, oracle):
+    for d in _inputs():
+        for level in (1, -3):
+            cp = zstd_amd.getCParams(level, len(d))
+            cap = zstd_amd.CompressBound(len(d))
+            buf = ctypes.create_string_buffer(cap + 1)
+            n = emu.emu_compress(buf, cap, d, len(d), cp[0], cp[2], cp[4], cp[5])
+            want = oracle.compress(d, level)
+            assert buf.raw[:n] == want, (len(d), level)
+            out = ctypes.create_string_buffer(len(d) + 1)
+            m = emu.emu_decompress(out, len(d), want, len(want))
+            assert m == len(d) and out.raw[:m] == d
+
+
+def test_emulated_decoder_errors(emu, oracle):
+    d = corpus.frames("json", 5000, 1, 3)[0]
+    c = oracle.compress(d, 1)
+    for x, cap in ((c[:-1], 6000), (c[:10], 6000), (b"\x00" * 20, 6000), (c + b"\x01", 6000), (c, len(d) - 1), (c + c[:5], 12000)):
+        out = ctypes.create_string_buffer(cap + 1)
+        m = emu.emu_decompress(out, cap, x, len(x))
+        want = oracle.decompress(x, cap)
+        assert isinstance(want, int) and m == 2 ** 64 + want, (len(x), cap, m, want)

@@ -1,0 +1,123 @@
+"""CPU tests of the oracle (oracle/zo_*.c): pinned against the reference-generated golden vectors in
+tests/golden/ and, where oracle/_ref has been built (dev container), against the reference's own C directly."""
+import hashlib
+import json
+import os
+import random
+
+import pytest
+
+from golden_inputs import small_inputs
+from zstd_amd import corpus
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _kats():
+    return json.load(open(os.path.join(HERE, "golden", "kat_small.json")))["cases"]
+
+
+def _tables():
+    return json.load(open(os.path.join(HERE, "golden", "corpus_frames.json")))["tables"]
+
+
+def test_survey_kats(oracle):
+    # verbatim small KATs probed from libzstd 1.5.5 at level 1
+    kats = {b"": "28b52ffd2000010000", b"a": "28b52ffd200109000061",
+            b"Hello World!": "28b52ffd200c61000048656c6c6f20576f726c6421",
+            bytes(1000): "28b52ffd60e8024d00001000000100e32b8005"}
+    for src, want in kats.items():
+        assert oracle.compress(src, 1).hex() == want
+
+
+def test_oracle_matches_golden_small(oracle):
+    inputs = dict(small_inputs())
+    for k in _kats():
+        src = bytes.fromhex(k["src_hex"]) if "src_hex" in k else inputs[k["name"]]
+        assert hashlib.sha256(src).hexdigest() == k["src_sha256"]
+        c = oracle.compress(src, k["level"])
+        assert isinstance(c, bytes), (k["name"], c)
+        assert len(c) == k["c_len"] and hashlib.sha256(c).hexdigest() == k["c_sha256"], k["name"]
+        if "c_hex" in k:
+            assert c.hex() == k["c_hex"]
+        assert oracle.decompress(c, max(len(src), 1)) == src
+
+
+def test_oracle_matches_golden_corpora(oracle):
+    for t in _tables():
+        frames = corpus.frames(t["kind"], t["frame_size"], t["n"], t["seed"])
+        for f, (clen, chash, shash) in zip(frames, t["rows"]):
+            assert hashlib.sha256(f).hexdigest()[:32] == shash, "corpus generator drifted"
+            c = oracle.compress(f, 1)
+            assert len(c) == clen and hashlib.sha256(c).hexdigest()[:32] == chash, (t["kind"], t["frame_size"])
+            assert oracle.decompress(c, len(f)) == f
+
+
+def test_oracle_vs_reference_random(oracle, ref):
+    rnd = random.Random(7)
+    for trial in range(150):
+        n = rnd.choice([0, 1, 7, 8, 63, 64, 65, 255, 256, 1000, 1024, 4096, 9000, 16384, 20000, 70000, 131072, 131073, 200000, 300000])
+        parts = []
+        while sum(map(len, parts)) < n:
+            k = rnd.randrange(5)
+            m = rnd.randrange(1, 4000)
+            parts.append([rnd.randbytes(m), bytes(m), rnd.randbytes(rnd.randrange(1, 30)) * (m // 8 + 1),
+                          (b"key=%d value=%x\n" % (rnd.randrange(99), rnd.getrandbits(20))) * (m // 16 + 1),
+                          bytes(rnd.choice(b"abcde") for _ in range(m))][k])
+        d = b"".join(parts)[:n]
+        for level in (1, -2):
+            a = ref.compress(d, level)
+            b = oracle.compress(d, level)
+            assert a == b, (trial, n, level)
+        assert oracle.decompress(a, max(n, 1)) == d
+        assert ref.decompress(b, max(n, 1)) == d
+
+
+def test_cparams_probe(oracle):
+    # SURVEY.md 8(a1) [probe] values
+    import ctypes
+    q = oracle.lib.zo_cparams_query
+    q.argtypes = [ctypes.c_int, ctypes.c_ulonglong, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_uint)]
+    out = (ctypes.c_uint * 7)()
+    for size, want in ((65536, (16, 12, 13, 1, 6, 0, 1)), (131072, (17, 12, 13, 1, 6, 0, 1)), (262144, (18, 13, 14, 1, 6, 0, 1)),
+                       (1024, (10, 10, 11, 1, 5, 0, 1)), (2 ** 64 - 1, (19, 13, 14, 1, 7, 0, 1))):
+        assert q(1, size, 0, 0, out) == 0
+        assert tuple(out) == want, size
+    assert q(3, 1 << 20, 0, 0, out) == 0 and tuple(out) == (20, 16, 17, 1, 5, 0, 2)
+
+
+def test_decode_errors_match_reference(oracle, ref):
+    d = corpus.frames("json", 5000, 1, 3)[0]
+    c = oracle.compress(d, 1)
+    cases = [c[:-1], c[:10], c[:4], b"\x00" * 20, c + b"\x01", c[:6] + bytes([c[6] ^ 0x40]) + c[7:], c + c, c + c[:5]]
+    for x in cases:
+        a, b = ref.decompress(x, 20000), oracle.decompress(x, 20000)
+        assert (a == b) or (isinstance(a, int) and isinstance(b, int)), (len(x), a if isinstance(a, int) else len(a), b if isinstance(b, int) else len(b))
+    # exact codes for the cases the Go tests rely on (zstd_test.go:90-117, 317-323)
+    assert oracle.decompress(c, len(d) - 1) == ref.decompress(c, len(d) - 1) == -70
+    assert oracle.error_name(-70) == "Destination buffer is too small"
+    bomb = bytes.fromhex("28b52ffd") + bytes([0xE0]) + (10 ** 12).to_bytes(8, "little") + b"\x00" * 3
+    assert oracle.decompress(bomb[:15], 100) == ref.decompress(bomb[:15], 100)
+
+
+def test_checksum_and_skippable_frames(oracle, ref):
+    import ctypes
+    lib = ref.lib
+    lib.ZSTD_createCCtx.restype = ctypes.c_void_p
+    lib.ZSTD_CCtx_setParameter.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    lib.ZSTD_compress2.restype = ctypes.c_size_t
+    lib.ZSTD_compress2.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    lib.ZSTD_freeCCtx.argtypes = [ctypes.c_void_p]
+    cctx = lib.ZSTD_createCCtx()
+    lib.ZSTD_CCtx_setParameter(cctx, 201, 1)   # ZSTD_c_checksumFlag
+    lib.ZSTD_CCtx_setParameter(cctx, 100, 3)   # level 3 (dfast) frames must decode too
+    d = corpus.frames("log", 50000, 1, 11)[0]
+    buf = ctypes.create_string_buffer(60000)
+    n = lib.ZSTD_compress2(cctx, buf, 60000, d, len(d))
+    lib.ZSTD_freeCCtx(cctx)
+    c = buf.raw[:n]
+    assert oracle.decompress(c, len(d)) == d
+    bad = c[:-1] + bytes([c[-1] ^ 1])
+    assert oracle.decompress(bad, len(d)) == ref.decompress(bad, len(d)) == -22
+    skip = (0x184D2A53).to_bytes(4, "little") + (7).to_bytes(4, "little") + b"1234567"
+    assert oracle.decompress(skip + c + skip + c, 2 * len(d)) == d + d

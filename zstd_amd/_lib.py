@@ -37,6 +37,8 @@ def _load():
         "zsa_batch_create": (V, [S]),
         "zsa_batch_free": (None, [V]),
         "zsa_batch_set_frame": (S, [V, S, V, S, V, S]),
+        "zsa_batch_set_frames_strided": (S, [V, S, V, S, c_size_p, V, S, S]),
+        "zsa_batch_link_src_sizes": (S, [V, V, V]),
         "zsa_batch_upload": (S, [V, S, V]),
         "zsa_compress_enqueue": (S, [V, I, V, V]),
         "zsa_decompress_enqueue": (S, [V, V, V]),

@@ -274,6 +274,23 @@ class DeviceBatch:
         if lib.zsa_isError(rc):
             raise ErrorCode(rc - 2 ** 64)
 
+    def set_frames_strided(self, n, src_ptr, src_stride, src_sizes, dst_ptr, dst_stride, dst_cap, stream=None):
+        sizes = None
+        if src_sizes is not None:
+            sizes = (ctypes.c_size_t * n)(*[int(x) for x in src_sizes])
+        rc = lib.zsa_batch_set_frames_strided(self.h, n, src_ptr, src_stride, sizes, dst_ptr, dst_stride, dst_cap)
+        if lib.zsa_isError(rc):
+            raise ErrorCode(rc - 2 ** 64)
+        self.n = n
+        rc = lib.zsa_batch_upload(self.h, n, stream)
+        if lib.zsa_isError(rc):
+            raise ErrorCode(rc - 2 ** 64)
+
+    def link_src_sizes(self, producer, stream=None):
+        rc = lib.zsa_batch_link_src_sizes(self.h, producer.h, stream)
+        if lib.zsa_isError(rc):
+            raise ErrorCode(rc - 2 ** 64)
+
     def compress(self, level=BestSpeed, cdict=None, stream=None):
         rc = lib.zsa_compress_enqueue(self.h, level, cdict, stream)
         if lib.zsa_isError(rc):

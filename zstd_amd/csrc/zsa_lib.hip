@@ -72,6 +72,12 @@ zsa_k_compress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ result
     }
 }
 
+__global__ void zsa_k_link_sizes(ZsaFrameDesc* __restrict__ frames, const u64* __restrict__ results, u32 n)
+{
+    u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { u64 const r = results[i]; frames[i].srcSize = (r > ZSA_ERR(ZSA_maxCode)) ? 0 : r; }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "libzstd_amd: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return ZSA_ERR(ZSA_GENERIC); } } while (0)
 
@@ -218,6 +224,25 @@ extern "C" size_t zsa_batch_set_frame(zsa_batch* b, size_t i, const void* d_src,
     if (!b || i >= b->maxFrames) return (size_t)ZSA_ERR(ZSA_parameter_outOfBound);
     b->h_frames[i].src = (const u8*)d_src; b->h_frames[i].dst = (u8*)d_dst;
     b->h_frames[i].srcSize = srcSize; b->h_frames[i].dstCapacity = dstCapacity;
+    return 0;
+}
+extern "C" size_t zsa_batch_set_frames_strided(zsa_batch* b, size_t nFrames, const void* d_src, size_t srcStride, const size_t* srcSizes,
+                                               void* d_dst, size_t dstStride, size_t dstCapacity)
+{
+    if (!b || nFrames > b->maxFrames) return (size_t)ZSA_ERR(ZSA_parameter_outOfBound);
+    for (size_t i = 0; i < nFrames; i++) {
+        b->h_frames[i].src = (const u8*)d_src + i * srcStride; b->h_frames[i].dst = (u8*)d_dst + i * dstStride;
+        b->h_frames[i].srcSize = srcSizes ? srcSizes[i] : srcStride; b->h_frames[i].dstCapacity = dstCapacity;
+    }
+    return 0;
+}
+extern "C" size_t zsa_batch_link_src_sizes(zsa_batch* consumer, const zsa_batch* producer, void* stream)
+{
+    if (!consumer || !producer || consumer->nFrames > producer->nFrames) return (size_t)ZSA_ERR(ZSA_parameter_outOfBound);
+    if (consumer->nFrames == 0) return 0;
+    u32 const n = (u32)consumer->nFrames;
+    hipLaunchKernelGGL(zsa_k_link_sizes, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, consumer->d_frames, producer->d_results, n);
+    HIPCHK(hipGetLastError());
     return 0;
 }
 extern "C" size_t zsa_batch_upload(zsa_batch* b, size_t nFrames, void* stream)
