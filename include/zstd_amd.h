@@ -90,6 +90,10 @@ const uint64_t* zsa_batch_device_results(const zsa_batch* b);
 /* geometry of the last launch (for roofline bookkeeping): workgroups launched, LDS bytes per workgroup */
 void zsa_batch_last_launch(const zsa_batch* b, unsigned* workgroups, unsigned* ldsBytes);
 
+/* diagnostics: enable/disable per-phase cycle accounting for launches of this batch; when `out` is non-NULL it first
+ * receives the 12 accumulated counters (shader-clock cycles of lane 0, summed over workgroups). */
+size_t zsa_batch_profile(zsa_batch* b, int enable, uint64_t* out, void* stream);
+
 /* resolved compression parameters {windowLog, chainLog, hashLog, searchLog, minMatch, targetLength, strategy}
  * for (level, srcSize, dictSize); mirrors ZSTD_getCParams_internal (zstd_compress.c:6960-6983) for the rows this
  * engine implements.  Returns 0, or 1 if the level is outside them.  mode: 0 noAttachDict, 1 attachDict, 2 createCDict. */

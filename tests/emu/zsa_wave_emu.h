@@ -62,6 +62,7 @@ ZSA_DEV unsigned wv_shfl(unsigned v, int srcLane) { const uint64_t* a = emu_coll
 ZSA_DEV unsigned wv_shfl_up(unsigned v, int delta) { int me = g_emu.cur; const uint64_t* a = emu_collect(v); return me >= delta ? (unsigned)a[me - delta] : v; }
 ZSA_DEV unsigned wv_shfl_xor(unsigned v, int mask) { int me = g_emu.cur; const uint64_t* a = emu_collect(v); return (unsigned)a[(me ^ mask) & 63]; }
 ZSA_DEV void wv_sync() { (void)emu_collect(0); }
+ZSA_DEV unsigned long long wv_clock() { return 0; }
 ZSA_DEV unsigned wv_atomic_add_lds(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 ZSA_DEV unsigned wv_atomic_or_lds(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
 ZSA_DEV unsigned wv_atomic_add_global(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }

@@ -45,6 +45,7 @@ def _load():
         "zsa_batch_results": (S, [V, c_size_p, V]),
         "zsa_batch_device_results": (V, [V]),
         "zsa_batch_last_launch": (None, [V, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]),
+        "zsa_batch_profile": (S, [V, I, ctypes.POINTER(ctypes.c_uint64), V]),
         "zsa_getCParams": (I, [I, ctypes.c_ulonglong, S, I, ctypes.POINTER(ctypes.c_uint)]),
         "zsa_device_count": (I, []),
         "zsa_version": (ctypes.c_char_p, []),

@@ -308,6 +308,11 @@ class DeviceBatch:
             raise ErrorCode(rc - 2 ** 64)
         return [out[i] for i in range(self.n)]
 
+    def profile(self, enable, read=False, stream=None):
+        out = (ctypes.c_uint64 * 12)() if read else None
+        lib.zsa_batch_profile(self.h, 1 if enable else 0, out, stream)
+        return list(out) if read else None
+
     def last_launch(self):
         wg, lds = ctypes.c_uint(), ctypes.c_uint()
         lib.zsa_batch_last_launch(self.h, ctypes.byref(wg), ctypes.byref(lds))

@@ -136,6 +136,10 @@ ZSA_DEV void zsa_st16(u8* p, u32 v) { p[0] = (u8)v; p[1] = (u8)(v >> 8); }
 ZSA_DEV void zsa_st24(u8* p, u32 v) { p[0] = (u8)v; p[1] = (u8)(v >> 8); p[2] = (u8)(v >> 16); }
 ZSA_DEV void zsa_st32(u8* p, u32 v) { p[0] = (u8)v; p[1] = (u8)(v >> 8); p[2] = (u8)(v >> 16); p[3] = (u8)(v >> 24); }
 
+// phase-cycle accounting (lane 0, shader clock); slots are named in zsa_lib.hip
+#define ZSA_NPROF 12
+#define ZSA_PROF(S, lane, slot) do { if ((lane) == 0) { u64 const t_ = wv_clock(); (S)->prof[slot] += t_ - (S)->profLast; (S)->profLast = t_; } } while (0)
+
 // One frame of a batch, as the kernels see it (all pointers are device pointers).
 struct ZsaFrameDesc {
     const u8* src; u8* dst;

@@ -48,6 +48,7 @@ struct ZsaDecShared {
     u64 result;                 // final return value of the frame walk
     u32 err;                    // first error raised inside the current block (0 = none)
     u32 u[16];
+    u64 prof[ZSA_NPROF], profLast;
 };
 enum { ZU_blockType, ZU_lastBlock, ZU_cSize, ZU_origSize, ZU_litMode, ZU_litSize, ZU_litOff, ZU_litCSize,
        ZU_nbSeq, ZU_seqOff, ZU_seqSize, ZU_batchN, ZU_streams, ZU_hufOff, ZU_hufCSize, ZU_tmp };
@@ -390,6 +391,7 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                              u8* litBuf, int lane)
 {
     u32 const expectedWriteSize = cap < ZSA_BLOCKSIZE_MAX ? (u32)cap : ZSA_BLOCKSIZE_MAX;
+    ZSA_PROF(S, lane, 0);
     // ---- literals header (zstd_decompress_block.c:120-322), lane 0
     if (lane == 0) {
         u32 err = 0, mode = 0, litSize = 0, litOff = 0, litCSize = 0, streams = 0, consumed = 0;
@@ -452,6 +454,7 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
             // huf_decompress.c HUF_decompress1X1_DCtx_wksp / HUF_decompress4X_hufOnly_wksp
             if (streams == 4 && (litSize == 0 || cSrcSize == 0)) { if (lane == 0) zsa_raise(S, ZSA_corruption_detected); wv_sync(); return 0; }
             u32 const hSize = zsa_huf_buildTable(S, cSrc, cSrcSize, lane);
+            ZSA_PROF(S, lane, 1);
             if (S->err) return 0;
             if (hSize >= cSrcSize) { if (lane == 0) zsa_raise(S, ZSA_corruption_detected); wv_sync(); return 0; }
             cSrc += hSize; cSrcSize -= hSize;
@@ -482,6 +485,7 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
         C.litEntropy = 1;
     }
     wv_sync();   // literal bytes written by some lanes are read by all below
+    ZSA_PROF(S, lane, 2);
 
     // ---- sequences header + tables (zstd_decompress_block.c:665-742), lane 0
     u32 const seqOff = S->u[ZU_seqOff];
@@ -520,6 +524,7 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
     wv_sync();
     if (S->err) return 0;
 
+    ZSA_PROF(S, lane, 3);
     u32 nbSeq = S->u[ZU_nbSeq];
     u32 outPos = op;                       // relative to C.dstBase
     u64 const oendRel = (u64)op + cap;     // relative end of the writable area
@@ -581,6 +586,7 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                 // last batch: exact-end check (zstd_decompress_block.c:1639), reported after the batch has executed
                 S->u[ZU_batchN] = (nbSeq == n) && (zsa_br_reload(b) < ZB_completed);
             }
+            ZSA_PROF(S, lane, 4);
             wv_sync();
             // -- execute the batch (zstd_decompress_block.c:873-1060 semantics)
             u32 const myLL = (u32)lane < n ? S->seqLL[lane] : 0;
@@ -613,6 +619,7 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
             }
             wv_sync();
             if (fencedPos < outPos) fencedPos = outPos;   // everything before this batch is visible now
+            ZSA_PROF(S, lane, 5);
             // matches, in order
             for (u32 i = 0; i < n; i++) {
                 u32 const ml = S->seqML[i], off = S->seqOF[i];
@@ -633,6 +640,7 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
             }
             outPos += totalOut; litPos += totalLit;
             nbSeq -= n;
+            ZSA_PROF(S, lane, 6);
             wv_sync();   // the batch arrays are rewritten by lane 0 next
             if (endBad) { if (lane == 0) zsa_raise(S, ZSA_corruption_detected); wv_sync(); return 0; }
         }
@@ -650,6 +658,7 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
         outPos += lastLL;
     }
     wv_sync();
+    ZSA_PROF(S, lane, 7);
     return outPos - op;
 }
 

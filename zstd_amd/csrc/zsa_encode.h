@@ -57,6 +57,7 @@ struct ZsaEncShared {
     u32 prevLL, prevOF, prevML, nextLL, nextOF, nextML;   // FSE repeat modes
     u32 err;
     u32 u[24];
+    u64 prof[ZSA_NPROF], profLast;
 };
 enum { EU_nbSeq, EU_litSize, EU_lastLL, EU_cSize, EU_litCSize, EU_hType, EU_single, EU_hSize, EU_useOld,
        EU_s0, EU_s1, EU_s2, EU_s3, EU_op, EU_tmp, EU_longType, EU_longPos, EU_raw };
@@ -772,6 +773,7 @@ ZSA_DEV u32 zsa_compressLiterals(ZsaEncShared* S, u8* dst, const u8* lit, u32 li
     }
     u32 const hSize = S->u[EU_hSize];
     u32 const repeatAfter = S->u[EU_tmp];
+    ZSA_PROF(S, lane, 3);
     u32 cLitSize = 0;   // 0 -> raw
     if (decision == 1) cLitSize = 1;
     else if (decision >= 2) {
@@ -937,6 +939,7 @@ ZSA_DEV u32 zsa_entropyCompress(ZsaEncShared* S, const u64* seq, u32 nbSeq, cons
         op += zsa_compressLiterals(S, op, lit, litSize, tmp, literalsDisabled, suspect, lane);
     }
     wv_sync();
+    ZSA_PROF(S, lane, 4);
     if (lane == 0) {
         u8* p = op;
         if (nbSeq < 128) *p++ = (u8)nbSeq;
@@ -986,6 +989,7 @@ ZSA_DEV u32 zsa_entropyCompress(ZsaEncShared* S, const u64* seq, u32 nbSeq, cons
             op += S->u[EU_tmp];
             wv_sync();
         }
+        ZSA_PROF(S, lane, 5);
         // zstd_compress_sequences.c:291-383 ZSTD_encodeSequences_body, lane 0
         if (lane == 0) {
             *seqHead = (u8)((types[0] << 6) + (types[1] << 4) + (types[2] << 2));
@@ -1020,6 +1024,7 @@ ZSA_DEV u32 zsa_entropyCompress(ZsaEncShared* S, const u64* seq, u32 nbSeq, cons
         }
         wv_sync();
         u32 const bitstreamSize = S->u[EU_tmp];
+        ZSA_PROF(S, lane, 6);
         op += bitstreamSize;
         wv_sync();
         if (lastCountSize && (lastCountSize + bitstreamSize) < 4) return 0;   // zstd_compress.c:2938-2944
@@ -1126,6 +1131,7 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
             if (blockStartIdx > maxDist) { u32 const nl = blockStartIdx - maxDist; if (dictLimit < nl) dictLimit = nl; }
         }
         u32 cSize = 0;
+        ZSA_PROF(S, lane, 0);
         if (blockSize >= 7) {   // zstd_compress.c:3156
             if (lane == 0) {
                 u32 rep[3] = { S->prevRep[0], S->prevRep[1], S->prevRep[2] };
@@ -1135,6 +1141,7 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
                 S->u[EU_nbSeq] = nbSeq; S->u[EU_lastLL] = lastLL;
             }
             wv_sync();
+            ZSA_PROF(S, lane, 1);
             u32 const nbSeq = S->u[EU_nbSeq], lastLL = S->u[EU_lastLL];
             // literal bytes = block bytes not covered by matches
             u32 litSize;
@@ -1144,6 +1151,7 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
             }
             zsa_gatherLiterals(S, W.seq, nbSeq, ip, blockSize, lastLL, W.lit, lane);
             wv_sync();
+            ZSA_PROF(S, lane, 2);
             cSize = zsa_entropyCompress(S, W.seq, nbSeq, W.lit, litSize, op + 3, blockSize, W.tmp, literalsDisabled, cd, lane);
             if (S->err) return ZSA_ERR(S->err);
             if (!isFirstBlock && cSize < 25) {   // zstd_compress.c:4258-4269 (ZSTD_isRLE :3413-3433)
@@ -1174,6 +1182,7 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
         op += cSize;
         isFirstBlock = 0;
         wv_sync();
+        ZSA_PROF(S, lane, 7);
     }
     return (u64)(op - dst);
 }

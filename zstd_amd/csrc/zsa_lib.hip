@@ -25,10 +25,11 @@ struct ZsaLaunchDict { const ZsaCDictDev* cd; const ZsaDDictDev* dd; };
 
 __global__ void __launch_bounds__(64, 2)
 zsa_k_decompress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
-                 u32* __restrict__ counter, u8* __restrict__ scratch, const ZsaDDictDev* dd)
+                 u32* __restrict__ counter, u8* __restrict__ scratch, const ZsaDDictDev* dd, u64* __restrict__ prof)
 {
     __shared__ ZsaDecShared S;
     __shared__ u32 nextFrame;
+    if (threadIdx.x == 0) { for (int i = 0; i < ZSA_NPROF; i++) S.prof[i] = 0; S.profLast = wv_clock(); }
     u8* const litBuf = scratch + (size_t)blockIdx.x * ZSA_DEC_SCRATCH_BYTES;
     for (;;) {
         if (threadIdx.x == 0) nextFrame = atomicAdd(counter, 1u);
@@ -37,19 +38,22 @@ zsa_k_decompress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ resu
         __syncthreads();
         if (f >= nFrames) break;
         ZsaFrameDesc const d = frames[f];
+        ZSA_PROF(&S, threadIdx.x, 11);
         u64 const r = zsa_decode_frames(&S, d.src, d.srcSize, d.dst, d.dstCapacity, litBuf, dd);
         if (threadIdx.x == 0) results[f] = r;
         __syncthreads();
     }
+    if (prof && threadIdx.x == 0) for (int i = 0; i < ZSA_NPROF; i++) atomicAdd((unsigned long long*)&prof[i], (unsigned long long)S.prof[i]);
 }
 
 __global__ void __launch_bounds__(64, 2)
 zsa_k_compress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
-               u32* __restrict__ counter, u8* __restrict__ scratch, int level, const ZsaCDictDev* cd)
+               u32* __restrict__ counter, u8* __restrict__ scratch, int level, const ZsaCDictDev* cd, u64* __restrict__ prof)
 {
     extern __shared__ __align__(16) u32 zsa_hashTable[];
     __shared__ ZsaEncShared S;
     __shared__ u32 nextFrame;
+    if (threadIdx.x == 0) { for (int i = 0; i < ZSA_NPROF; i++) S.prof[i] = 0; S.profLast = wv_clock(); }
     u8* const wg = scratch + (size_t)blockIdx.x * ZSA_ENC_SCRATCH_BYTES;
     ZsaEncScratch W;
     W.seq = (u64*)wg; W.lit = wg + (size_t)ZSA_SEQ_CAP * 8; W.tmp = W.lit + ZSA_LIT_CAP;
@@ -60,6 +64,7 @@ zsa_k_compress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ result
         __syncthreads();
         if (f >= nFrames) break;
         ZsaFrameDesc const d = frames[f];
+        ZSA_PROF(&S, threadIdx.x, 11);
         ZsaCParams cp;
         u64 r;
         if (zsa_resolveCParams(&cp, level, d.srcSize, 0, zsa_cpm_noAttachDict) || cp.strat != 1) r = ZSA_ERR(ZSA_parameter_unsupported);
@@ -70,6 +75,7 @@ zsa_k_compress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ result
         if (threadIdx.x == 0) results[f] = r;
         __syncthreads();
     }
+    if (prof && threadIdx.x == 0) for (int i = 0; i < ZSA_NPROF; i++) atomicAdd((unsigned long long*)&prof[i], (unsigned long long)S.prof[i]);
 }
 
 __global__ void zsa_k_link_sizes(ZsaFrameDesc* __restrict__ frames, const u64* __restrict__ results, u32 n)
@@ -94,6 +100,7 @@ struct zsa_batch_s {
     int  numCU;
     u64  maxSrcSize;
     unsigned lastWG, lastLDS;
+    u64* d_prof; int profOn;
 };
 
 extern "C" int zsa_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
@@ -193,6 +200,7 @@ extern "C" void zsa_batch_free(zsa_batch* b)
     if (b->d_results) (void)hipFree(b->d_results);
     if (b->d_counter) (void)hipFree(b->d_counter);
     if (b->d_scratch) (void)hipFree(b->d_scratch);
+    if (b->d_prof) (void)hipFree(b->d_prof);
     free(b);
 }
 #define ZSA_MAX_WG_PER_CU 8
@@ -215,6 +223,7 @@ extern "C" zsa_batch* zsa_batch_create(size_t maxFrames)
            && hipMalloc((void**)&b->d_frames, maxFrames * sizeof(ZsaFrameDesc)) == hipSuccess
            && hipMalloc((void**)&b->d_results, maxFrames * sizeof(u64)) == hipSuccess
            && hipMalloc((void**)&b->d_counter, 256) == hipSuccess
+           && hipMalloc((void**)&b->d_prof, ZSA_NPROF * sizeof(u64)) == hipSuccess
            && hipMalloc((void**)&b->d_scratch, b->scratchBytes) == hipSuccess;
     if (!ok) { fprintf(stderr, "libzstd_amd: device allocation failed (%zu frames)\n", maxFrames); zsa_batch_free(b); return NULL; }
     return b;
@@ -285,7 +294,7 @@ extern "C" size_t zsa_compress_enqueue(zsa_batch* b, int level, const zsa_CDict*
     unsigned const grid = zsa_grid(b, ldsPerWG);
     HIPCHK(hipMemsetAsync(b->d_counter, 0, 256, (hipStream_t)stream));
     hipLaunchKernelGGL(zsa_k_compress, dim3(grid), dim3(64), dynLds, (hipStream_t)stream,
-                       b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter, b->d_scratch, level, (const ZsaCDictDev*)nullptr);
+                       b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter, b->d_scratch, level, (const ZsaCDictDev*)nullptr, b->profOn ? b->d_prof : (u64*)nullptr);
     HIPCHK(hipGetLastError());
     b->lastWG = grid; b->lastLDS = (unsigned)ldsPerWG;
     return 0;
@@ -299,7 +308,7 @@ extern "C" size_t zsa_decompress_enqueue(zsa_batch* b, const zsa_DDict* ddict, v
     unsigned const grid = zsa_grid(b, ldsPerWG);
     HIPCHK(hipMemsetAsync(b->d_counter, 0, 256, (hipStream_t)stream));
     hipLaunchKernelGGL(zsa_k_decompress, dim3(grid), dim3(64), 0, (hipStream_t)stream,
-                       b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter, b->d_scratch, (const ZsaDDictDev*)nullptr);
+                       b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter, b->d_scratch, (const ZsaDDictDev*)nullptr, b->profOn ? b->d_prof : (u64*)nullptr);
     HIPCHK(hipGetLastError());
     b->lastWG = grid; b->lastLDS = (unsigned)ldsPerWG;
     return 0;
@@ -310,6 +319,14 @@ extern "C" size_t zsa_batch_results(zsa_batch* b, size_t* outSize, void* stream)
     if (b->nFrames) HIPCHK(hipMemcpyAsync(b->h_results, b->d_results, b->nFrames * sizeof(u64), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     for (size_t i = 0; i < b->nFrames; i++) outSize[i] = (size_t)b->h_results[i];
+    return 0;
+}
+extern "C" size_t zsa_batch_profile(zsa_batch* b, int enable, uint64_t* out /* ZSA_NPROF words or NULL */, void* stream)
+{   // diagnostics: per-phase shader-clock cycles of lane 0 summed over all workgroups since profiling was enabled
+    if (!b) return kErrGeneric;
+    if (out) { HIPCHK(hipStreamSynchronize((hipStream_t)stream)); HIPCHK(hipMemcpy(out, b->d_prof, ZSA_NPROF * sizeof(u64), hipMemcpyDeviceToHost)); }
+    if (enable && !b->profOn) HIPCHK(hipMemset(b->d_prof, 0, ZSA_NPROF * sizeof(u64)));
+    b->profOn = enable;
     return 0;
 }
 extern "C" const uint64_t* zsa_batch_device_results(const zsa_batch* b) { return b ? b->d_results : NULL; }

@@ -17,6 +17,7 @@ ZSA_DEV unsigned wv_shfl_up(unsigned v, int delta) { return (unsigned)__shfl_up(
 ZSA_DEV unsigned wv_shfl_xor(unsigned v, int mask) { return (unsigned)__shfl_xor((int)v, mask, 64); }
 // Workgroup == one wave here: orders LDS and global accesses between the lanes of the wave.
 ZSA_DEV void wv_sync() { __syncthreads(); }
+ZSA_DEV unsigned long long wv_clock() { return (unsigned long long)clock64(); }
 ZSA_DEV unsigned wv_atomic_add_lds(unsigned* p, unsigned v) { return atomicAdd(p, v); }
 ZSA_DEV unsigned wv_atomic_or_lds(unsigned* p, unsigned v) { return atomicOr(p, v); }
 ZSA_DEV unsigned wv_atomic_add_global(unsigned* p, unsigned v) { return atomicAdd(p, v); }
