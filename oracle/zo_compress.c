@@ -88,6 +88,7 @@ int zo_getCParams(zo_cparams* out, int level, u64 srcSizeHint, size_t dictSize, 
 /* ------------------------------------------------------------------ match state */
 typedef struct {
     const u8* base;        /* window.base: index i <-> base + i */
+    const u8* dictBase;    /* window.dictBase: indices in [lowLimit, dictLimit) live at dictBase + i (extDict) */
     u32 dictLimit, lowLimit;
     u32 loadedDictEnd;
     u32* hashTable;
@@ -127,6 +128,14 @@ static u32 zo_lowestPrefixIndex(const zo_matchstate* ms, u32 curr, u32 windowLog
 {
     u32 const maxDistance = 1U << windowLog;
     u32 const lowestValid = ms->dictLimit;
+    u32 const withinWindow = (curr - lowestValid > maxDistance) ? curr - maxDistance : lowestValid;
+    return (ms->loadedDictEnd != 0) ? lowestValid : withinWindow;
+}
+/* zstd_compress_internal.h:1290-1302 ZSTD_getLowestMatchIndex */
+static u32 zo_lowestMatchIndex(const zo_matchstate* ms, u32 curr, u32 windowLog)
+{
+    u32 const maxDistance = 1U << windowLog;
+    u32 const lowestValid = ms->lowLimit;
     u32 const withinWindow = (curr - lowestValid > maxDistance) ? curr - maxDistance : lowestValid;
     return (ms->loadedDictEnd != 0) ? lowestValid : withinWindow;
 }
@@ -392,6 +401,145 @@ cleanup:
     return (size_t)(iend - anchor);
 }
 
+/* ------------------------------------------------------------------ the level-1 parse, dictionary as extDict */
+/* zstd_fast.c:685-936 ZSTD_compressBlock_fast_extDict_generic: the window is two segments, the dictionary
+ * content at dictBase + [lowLimit, dictLimit) and the input at base + [dictLimit, ...). */
+static size_t zo_fast_extDict(zo_matchstate* ms, zo_seqstore* ss, u32 rep[3], const u8* src, size_t srcSize)
+{
+    u32* const hashTable = ms->hashTable;
+    u32 const hlog = ms->cp.hlog, mls = ms->cp.mml;
+    size_t const stepSize = ms->cp.tlen + !(ms->cp.tlen) + 1;
+    const u8* const base = ms->base;
+    const u8* const dictBase = ms->dictBase;
+    const u8* const istart = src;
+    const u8* anchor = istart;
+    u32 const endIndex = (u32)((size_t)(istart - base) + srcSize);
+    u32 const lowLimit = zo_lowestMatchIndex(ms, endIndex, ms->cp.wlog);
+    u32 const dictStartIndex = lowLimit;
+    const u8* const dictStart = dictBase + dictStartIndex;
+    u32 const dictLimit = ms->dictLimit;
+    u32 const prefixStartIndex = dictLimit < lowLimit ? lowLimit : dictLimit;
+    const u8* const prefixStart = base + prefixStartIndex;
+    const u8* const dictEnd = dictBase + prefixStartIndex;
+    const u8* const iend = istart + srcSize;
+    const u8* const ilimit = iend - 8;
+    u32 offset_1 = rep[0], offset_2 = rep[1], offsetSaved1 = 0, offsetSaved2 = 0;
+    const u8* ip0 = istart;
+    size_t const kStepIncr = 1 << (8 - 1);
+
+    if (prefixStartIndex == dictStartIndex) return zo_fast_noDict(ms, ss, rep, src, srcSize);   /* :737-738 */
+    {   u32 const curr = (u32)(ip0 - base);
+        u32 const maxRep = curr - dictStartIndex;
+        if (offset_2 >= maxRep) { offsetSaved2 = offset_2; offset_2 = 0; }
+        if (offset_1 >= maxRep) { offsetSaved1 = offset_1; offset_1 = 0; }
+    }
+    for (;;) {   /* label _start */
+        size_t step = stepSize;
+        const u8* nextStep = ip0 + kStepIncr;
+        const u8* ip1 = ip0 + 1;
+        const u8* ip2 = ip0 + step;
+        const u8* ip3 = ip2 + 1;
+        u32 hash0, hash1, idx, current0 = 0, offcode = 0;
+        const u8* idxBase;
+        const u8* match0 = NULL;
+        const u8* matchEnd = NULL;
+        size_t mLength = 0;
+        int found = 0;   /* 1 repcode at ip2, 2 table match at ip0 */
+
+        if (ip3 >= ilimit) break;
+        hash0 = zo_hashPtr(ip0, hlog, mls);
+        hash1 = zo_hashPtr(ip1, hlog, mls);
+        idx = hashTable[hash0];
+        idxBase = idx < prefixStartIndex ? dictBase : base;
+        do {
+            {   u32 const current2 = (u32)(ip2 - base);
+                u32 const repIndex = current2 - offset_1;
+                const u8* const repBase = repIndex < prefixStartIndex ? dictBase : base;
+                u32 rval;
+                if (((u32)(prefixStartIndex - repIndex) >= 4) & (offset_1 > 0)) rval = zo_rd32(repBase + repIndex);
+                else rval = zo_rd32(ip2) ^ 1;
+                current0 = (u32)(ip0 - base);
+                hashTable[hash0] = current0;
+                if (zo_rd32(ip2) == rval) {
+                    ip0 = ip2;
+                    match0 = repBase + repIndex;
+                    matchEnd = repIndex < prefixStartIndex ? dictEnd : iend;
+                    mLength = ip0[-1] == match0[-1];
+                    ip0 -= mLength; match0 -= mLength;
+                    offcode = 1;
+                    mLength += 4;
+                    found = 1;
+                    break;
+                }
+            }
+            {   u32 const mval = idx >= dictStartIndex ? zo_rd32(idxBase + idx) : zo_rd32(ip0) ^ 1;
+                if (zo_rd32(ip0) == mval) { found = 2; break; }
+            }
+            idx = hashTable[hash1];
+            idxBase = idx < prefixStartIndex ? dictBase : base;
+            hash0 = hash1;
+            hash1 = zo_hashPtr(ip2, hlog, mls);
+            ip0 = ip1; ip1 = ip2; ip2 = ip3;
+            current0 = (u32)(ip0 - base);
+            hashTable[hash0] = current0;
+            {   u32 const mval = idx >= dictStartIndex ? zo_rd32(idxBase + idx) : zo_rd32(ip0) ^ 1;
+                if (zo_rd32(ip0) == mval) { found = 2; break; }
+            }
+            idx = hashTable[hash1];
+            idxBase = idx < prefixStartIndex ? dictBase : base;
+            hash0 = hash1;
+            hash1 = zo_hashPtr(ip2, hlog, mls);
+            ip0 = ip1; ip1 = ip2;
+            ip2 = ip0 + step;
+            ip3 = ip1 + step;
+            if (ip2 >= nextStep) { step++; nextStep += kStepIncr; }
+        } while (ip3 < ilimit);
+        if (!found) break;
+
+        if (found == 2) {   /* label _offset */
+            u32 const offset = current0 - idx;
+            const u8* const lowMatchPtr = idx < prefixStartIndex ? dictStart : prefixStart;
+            matchEnd = idx < prefixStartIndex ? dictEnd : iend;
+            match0 = idxBase + idx;
+            offset_2 = offset_1;
+            offset_1 = offset;
+            offcode = offset + 3;
+            mLength = 4;
+            while (((ip0 > anchor) & (match0 > lowMatchPtr)) && (ip0[-1] == match0[-1])) { ip0--; match0--; mLength++; }
+        }
+        /* label _match */
+        mLength += zo_count_2segments(ip0 + mLength, match0 + mLength, iend, matchEnd, prefixStart);
+        zo_storeSeq(ss, (size_t)(ip0 - anchor), anchor, offcode, mLength);
+        ip0 += mLength;
+        anchor = ip0;
+        if (ip1 < ip0) hashTable[hash1] = (u32)(ip1 - base);
+        if (ip0 <= ilimit) {
+            hashTable[zo_hashPtr(base + current0 + 2, hlog, mls)] = current0 + 2;
+            hashTable[zo_hashPtr(ip0 - 2, hlog, mls)] = (u32)(ip0 - 2 - base);
+            while (ip0 <= ilimit) {
+                u32 const repIndex2 = (u32)(ip0 - base) - offset_2;
+                const u8* const repMatch2 = repIndex2 < prefixStartIndex ? dictBase + repIndex2 : base + repIndex2;
+                if ((((u32)((prefixStartIndex - 1) - repIndex2) >= 3) & (offset_2 > 0)) && (zo_rd32(repMatch2) == zo_rd32(ip0))) {
+                    const u8* const repEnd2 = repIndex2 < prefixStartIndex ? dictEnd : iend;
+                    size_t const repLength2 = zo_count_2segments(ip0 + 4, repMatch2 + 4, iend, repEnd2, prefixStart) + 4;
+                    { u32 const t = offset_2; offset_2 = offset_1; offset_1 = t; }
+                    zo_storeSeq(ss, 0, anchor, 1, repLength2);
+                    hashTable[zo_hashPtr(ip0, hlog, mls)] = (u32)(ip0 - base);
+                    ip0 += repLength2;
+                    anchor = ip0;
+                    continue;
+                }
+                break;
+            }
+        }
+    }
+    /* label _cleanup :860-874 */
+    offsetSaved2 = ((offsetSaved1 != 0) && (offset_1 != 0)) ? offsetSaved1 : offsetSaved2;
+    rep[0] = offset_1 ? offset_1 : offsetSaved1;
+    rep[1] = offset_2 ? offset_2 : offsetSaved2;
+    return (size_t)(iend - anchor);
+}
+
 /* ------------------------------------------------------------------ frame writer */
 /* zstd_compress.c:4474-4520 ZSTD_writeFrameHeader (contentSizeFlag=1, checksumFlag=0, noDictIDFlag=0) */
 static size_t zo_writeFrameHeader(u8* op, u32 windowLog, u64 pledgedSrcSize, u32 dictID)
@@ -431,10 +579,36 @@ static void zo_initEntropyNone(zo_cblockstate* bs)
     bs->entropy.ll_repeat = bs->entropy.of_repeat = bs->entropy.ml_repeat = zo_rep_none;
 }
 
+/* zstd_fast.c:50-82 ZSTD_fillHashTableForCCtx with ZSTD_dtlm_fast (every third position), and :15-48
+ * ZSTD_fillHashTableForCDict with ZSTD_dtlm_full (tagged entries, in-between positions only into empty cells) */
+static void zo_fillHashTable(u32* hashTable, const zo_cparams* cp, const u8* base, u32 nextToUpdate, const u8* end, int forCDict)
+{
+    u32 const hBits = cp->hlog + (forCDict ? 8 : 0);
+    u32 const mls = cp->mml;
+    const u8* ip = base + nextToUpdate;
+    const u8* const iend = end - 8;
+    for (; ip + 3 < iend + 2; ip += 3) {
+        u32 const curr = (u32)(ip - base);
+        u32 const h0 = zo_hashPtr(ip, hBits, mls);
+        if (!forCDict) { hashTable[h0] = curr; continue; }
+        hashTable[h0 >> 8] = (curr << 8) | (h0 & 0xFF);   /* zstd_compress_internal.h ZSTD_writeTaggedIndex */
+        {   u32 p;
+            for (p = 1; p < 3; ++p) {
+                u32 const h = zo_hashPtr(ip + p, hBits, mls);
+                if (hashTable[h >> 8] == 0) hashTable[h >> 8] = ((curr + p) << 8) | (h & 0xFF);
+            }
+        }
+    }
+}
+
+enum { zo_dm_none = 0, zo_dm_attach = 1, zo_dm_copy = 2, zo_dm_load = 3 };
+
 /* One frame, begin to end: zstd_compress.c:5001-5046 (begin), :4573-4632 (continue), :4392-4471 (frameChunk),
- * :4222-4283 (block), :5107-5144 (epilogue).  `cdict` may be NULL. */
+ * :4222-4283 (block), :5107-5144 (epilogue).  `cdict` may be NULL (dictMode zo_dm_none); otherwise dictMode says how
+ * ZSTD_compressBegin_internal brought the dictionary in: attached in place (:2270-2329), tables copied
+ * (:2347-2426), or content re-loaded into the working tables (:5027-5044). */
 static size_t zo_compressFrame(u8* dst, size_t dstCapacity, const u8* src, size_t srcSize,
-                               zo_cparams cp, const zo_cdict* cdict, zo_seq_dump_fn dump, void* dumpArg)
+                               zo_cparams cp, const zo_cdict* cdict, int dictMode, zo_seq_dump_fn dump, void* dumpArg)
 {
     u8* op = dst;
     size_t remaining = srcSize;
@@ -469,23 +643,44 @@ static size_t zo_compressFrame(u8* dst, size_t dstCapacity, const u8* src, size_
     if (!ms.hashTable || !ss.seq || !ss.lit || !codeWksp) { result = ZO_ERR(memory_allocation); goto done; }
     zo_initEntropyNone(bsPrev);
 
-    if (cdict == NULL) {
-        /* zstd_compress_internal.h:1232-1285 window_init + first window_update: first byte has index 2 */
-        ms.base = src - 2; ms.dictLimit = 2; ms.lowLimit = 2; ms.loadedDictEnd = 0; ms.dms = NULL;
-    } else {
-        /* zstd_compress.c:2270-2329 ZSTD_resetCCtx_byAttachingCDict: window continues right after the dictionary */
-        u32 const cdictEnd = cdict->endIndex;
+    /* zstd_compress_internal.h:1232-1285 window_init + first window_update: first byte has index 2 */
+    ms.base = src - 2; ms.dictBase = src - 2; ms.dictLimit = 2; ms.lowLimit = 2; ms.loadedDictEnd = 0; ms.dms = NULL;
+    if (cdict != NULL) {
+        u32 const cdictEnd = cdict->endIndex;          /* window.nextSrc - window.base of the dictionary's match state */
         u32 const cdictLen = cdictEnd - 2;
-        if (cdictLen == 0) { ms.base = src - 2; ms.dictLimit = 2; ms.lowLimit = 2; ms.loadedDictEnd = 0; ms.dms = NULL; }
-        else {
-            ms.dms = cdict;
-            /* window.nextSrc = base + cdictEnd (base = " "), then the non-contiguous update rebases */
-            ms.base = src - cdictEnd;
-            ms.dictLimit = cdictEnd;
-            ms.lowLimit = cdictEnd;   /* former dictLimit(2..cdictEnd) segment becomes lowLimit; "too small extDict" rule may apply, see below */
-            ms.loadedDictEnd = cdictEnd;
+        if (dictMode == zo_dm_attach) {
+            /* :2301-2320: the working window is cleared at cdictEnd, then ZSTD_window_update (non contiguous,
+             * empty former prefix => no extDict) rebases so that the input starts at index cdictEnd */
+            if (cdictLen != 0) {
+                ms.dms = cdict;
+                ms.base = src - cdictEnd; ms.dictBase = ms.base;
+                ms.dictLimit = cdictEnd; ms.lowLimit = cdictEnd;
+                ms.loadedDictEnd = cdictEnd;
+            }
+        } else {
+            /* zo_dm_copy :2376-2417 (tables untagged, window/loadedDictEnd copied) or zo_dm_load :5030-5044
+             * (content indexed again with the working parameters).  Either way the dictionary content is the
+             * window's previous segment [2, cdictEnd) and the input a new, non-contiguous one:
+             * zstd_compress_internal.h:1262-1274 turns the former into the extDict. */
+            size_t i;
+            if (dictMode == zo_dm_copy) {
+                for (i = 0; i < ((size_t)1 << cp.hlog); i++) ms.hashTable[i] = cdict->hashTable[i] >> 8;
+            } else if (cdict->isLoaded && cdictLen > 8) {
+                /* zstd_compress.c:4740-4761: only the suffix the tables can index is inserted */
+                u32 const maxDictSize = 8U << (cp.hlog > cp.clog ? (cp.hlog < 28 ? cp.hlog : 28) : (cp.clog < 28 ? cp.clog : 28));
+                u32 const from = cdictLen > maxDictSize ? cdictEnd - maxDictSize : 2;
+                if (cdictEnd - from > 8)
+                    zo_fillHashTable(ms.hashTable, &cp, cdict->content - 2, from, cdict->content + cdictLen, 0);
+            }
+            if (cdictLen != 0) {
+                ms.dictBase = cdict->content - 2;
+                ms.base = src - cdictEnd;
+                ms.lowLimit = 2; ms.dictLimit = cdictEnd;
+                if (ms.dictLimit - ms.lowLimit < 8) ms.lowLimit = ms.dictLimit;   /* too small extDict */
+            }
+            ms.loadedDictEnd = cdict->isLoaded ? cdictEnd : 0;
         }
-        *bsPrev = cdict->cbs;   /* :2322 copy block state (entropy + reps) */
+        *bsPrev = cdict->cbs;   /* :2326 / :2423 copy block state; zo_dm_load parses the same header again (:4942) */
     }
 
     op += zo_writeFrameHeader(op, cp.wlog, (u64)srcSize, cdict ? cdict->dictID : 0);
@@ -518,8 +713,10 @@ static size_t zo_compressFrame(u8* dst, size_t dstCapacity, const u8* src, size_
             size_t lastLL;
             ss.nbSeq = 0; ss.litSize = 0; ss.longLengthType = 0;
             bsNext->rep[0] = bsPrev->rep[0]; bsNext->rep[1] = bsPrev->rep[1]; bsNext->rep[2] = bsPrev->rep[2];
-            if (ms.dms) lastLL = zo_fast_dictMatchState(&ms, &ss, bsNext->rep, ip, blockSize);
-            else        lastLL = zo_fast_noDict(&ms, &ss, bsNext->rep, ip, blockSize);
+            /* zstd_compress_internal.h:971-978 ZSTD_matchState_dictMode */
+            if (ms.lowLimit < ms.dictLimit) lastLL = zo_fast_extDict(&ms, &ss, bsNext->rep, ip, blockSize);
+            else if (ms.dms)                lastLL = zo_fast_dictMatchState(&ms, &ss, bsNext->rep, ip, blockSize);
+            else                            lastLL = zo_fast_noDict(&ms, &ss, bsNext->rep, ip, blockSize);
             memcpy(ss.lit + ss.litSize, ip + blockSize - lastLL, lastLL);
             ss.litSize += lastLL;
             if (dump) dump(dumpArg, ss.seq, ss.nbSeq, ss.lit, ss.litSize, bsNext->rep);
@@ -574,7 +771,7 @@ size_t zo_compress_dump(void* dst, size_t dstCapacity, const void* src, size_t s
         return ZO_ERR(parameter_unsupported);   /* oracle scope: ZSTD_fast levels only */
     if (srcSize > 0xE0000000u) return ZO_ERR(srcSize_wrong);   /* index overflow correction not restated */
     if (src == NULL) src = empty;
-    return zo_compressFrame((u8*)dst, dstCapacity, (const u8*)src, srcSize, cp, NULL, dump, dumpArg);
+    return zo_compressFrame((u8*)dst, dstCapacity, (const u8*)src, srcSize, cp, NULL, zo_dm_none, dump, dumpArg);
 }
 size_t zo_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level)
 {

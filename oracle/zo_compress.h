@@ -14,13 +14,15 @@ typedef struct {
 
 /* digested dictionary for compression (zstd_compress.c ZSTD_CDict_s, the parts this path reads) */
 typedef struct zo_cdict_s {
-    u8*  content; size_t contentSize;     /* dictionary content (after the entropy header, if any) */
+    u8*  dictBuf; size_t dictSize;        /* private copy of the whole dictionary (cdict->dictContent / dictContentSize) */
+    const u8* content; size_t contentSize;/* the part that entered the window: after the entropy header, if any */
+    int  isLoaded;                        /* 0 when the dictionary was ignored (NULL or < 8 bytes) */
     u32  dictID;
     zo_cparams cp;                        /* cpm_createCDict parameters */
     u32* hashTable;                       /* tagged: (index << 8) | tag, zstd_fast.c:15-48 */
     u32  endIndex;                        /* window.nextSrc - base == 2 + contentSize */
     zo_cblockstate cbs;                   /* entropy tables + reps loaded from the dictionary */
-    int  level;
+    int  level;                           /* cdict->compressionLevel */
 } zo_cdict;
 
 size_t zo_entropyCompressSeqStore(const zo_seqstore* ss, const zo_entropy* prev, zo_entropy* next,

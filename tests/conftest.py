@@ -47,6 +47,50 @@ class _Lib:
             return -(2 ** 64 - r)
         return buf.raw[:r]
 
+    # ---- dictionary path (zstd_bulk.go): ZSTD_createCDict / compress_usingCDict / createDDict / decompress_usingDDict
+    def cdict(self, d, level):
+        S, V = ctypes.c_size_t, ctypes.c_void_p
+        f = self._fn("createCDict", V, [ctypes.c_char_p, S, ctypes.c_int])
+        return f(d, len(d), level)
+
+    def ddict(self, d):
+        S, V = ctypes.c_size_t, ctypes.c_void_p
+        f = self._fn("createDDict", V, [ctypes.c_char_p, S])
+        return f(d, len(d))
+
+    def free_cdict(self, h):
+        self._fn("freeCDict", None if self.prefix == "zo_" else ctypes.c_size_t, [ctypes.c_void_p])(h)
+
+    def free_ddict(self, h):
+        self._fn("freeDDict", None if self.prefix == "zo_" else ctypes.c_size_t, [ctypes.c_void_p])(h)
+
+    def compress_cdict(self, data, h):
+        S, V = ctypes.c_size_t, ctypes.c_void_p
+        cap = self.bound_(len(data))
+        buf = ctypes.create_string_buffer(cap + 1)
+        if self.prefix == "zo_":
+            r = self._fn("compress_usingCDict", S, [V, S, ctypes.c_char_p, S, V])(buf, cap, data, len(data), h)
+        else:
+            if not hasattr(self, "_cctx"):
+                self._cctx = self._fn("createCCtx", V, [])()
+            r = self._fn("compress_usingCDict", S, [V, V, S, ctypes.c_char_p, S, V])(self._cctx, buf, cap, data, len(data), h)
+        if self.isError_(r):
+            return -(2 ** 64 - r)
+        return buf.raw[:r]
+
+    def decompress_ddict(self, data, cap, h):
+        S, V = ctypes.c_size_t, ctypes.c_void_p
+        buf = ctypes.create_string_buffer(cap + 1)
+        if self.prefix == "zo_":
+            r = self._fn("decompress_usingDDict", S, [V, S, ctypes.c_char_p, S, V])(buf, cap, data, len(data), h)
+        else:
+            if not hasattr(self, "_dctx"):
+                self._dctx = self._fn("createDCtx", V, [])()
+            r = self._fn("decompress_usingDDict", S, [V, V, S, ctypes.c_char_p, S, V])(self._dctx, buf, cap, data, len(data), h)
+        if self.isError_(r):
+            return -(2 ** 64 - r)
+        return buf.raw[:r]
+
     def error_name(self, code):
         return self.getErrorName_(ctypes.c_size_t((-code) if code > 0 else (2 ** 64 + code) if code < 0 else 0)).decode()
 

@@ -6,8 +6,11 @@
 #include "zsa_decode.h"
 #ifdef ZSA_EMU_ENCODE
 #include "zsa_encode.h"
+#include "zsa_dict.h"
 #endif
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 
 ZsaEmu g_emu;
 static emu_kernel_fn g_fn; static void* g_arg;
@@ -56,11 +59,11 @@ extern "C" size_t emu_decompress(void* dst, size_t cap, const void* src, size_t 
 }
 
 #ifdef ZSA_EMU_ENCODE
-struct EncArgs { ZsaEncShared* S; u32* ht; ZsaEncParams P; const u8* src; u64 srcSize; u8* dst; u64 cap; ZsaEncScratch W; const ZsaCDictDev* cd; u64 result; };
+struct EncArgs { ZsaEncShared* S; u32* ht; ZsaEncParams P; const u8* src; u64 srcSize; u8* dst; u64 cap; ZsaEncScratch W; const ZsaCDictDev* cd; int dictMode; u64 result; };
 static void enc_entry(void* a)
 {
     EncArgs* A = (EncArgs*)a;
-    u64 r = zsa_encode_frame(A->S, A->ht, A->P, A->src, A->srcSize, A->dst, A->cap, A->W, A->cd);
+    u64 r = zsa_encode_frame(A->S, A->ht, A->P, A->src, A->srcSize, A->dst, A->cap, A->W, A->cd, A->dictMode);
     if (wv_lane() == 0) A->result = r;
 }
 extern "C" size_t emu_compress(void* dst, size_t cap, const void* src, size_t n, unsigned wlog, unsigned hlog, unsigned mml, unsigned tlen)
@@ -71,8 +74,73 @@ extern "C" size_t emu_compress(void* dst, size_t cap, const void* src, size_t n,
     static u8* lit = (u8*)malloc(ZSA_BLOCKSIZE_MAX + 128);
     static u8* tmp = (u8*)malloc(ZSA_BLOCKSIZE_MAX * 2 + 512);
     static const u8 empty[16] = {0};
-    EncArgs A = { &S, ht, { wlog, hlog, mml, tlen }, n ? (const u8*)src : empty + 8, n, (u8*)dst, cap, { seq, lit, tmp }, nullptr, 0 };
+    EncArgs A = { &S, ht, { wlog, hlog, mml, tlen }, n ? (const u8*)src : empty + 8, n, (u8*)dst, cap, { seq, lit, tmp }, nullptr, 0, 0 };
     emu_run_wave(enc_entry, &A);
+    return (size_t)A.result;
+}
+
+// ---- dictionaries: the digests the product builds on the device, built here by the same code on emulated lanes
+struct EmuCDict { ZsaCDictDev cd; u8* dict; u32* table; };
+struct EmuDDict { ZsaDDictDev dd; ZsaDDictTables T; u8* dict; };
+struct DigArgs { ZsaEncShared* SE; ZsaDecShared* SD; EmuCDict* c; EmuDDict* d; u32 dictSize; ZsaCParams cp; int level; u32 result; };
+static void digc_entry(void* a)
+{
+    DigArgs* A = (DigArgs*)a;
+    u32 r = zsa_digest_cdict(A->SE, A->SD, A->c->dict, A->dictSize, A->cp, A->level, &A->c->cd, A->c->table);
+    if (wv_lane() == 0) A->result = r;
+}
+static void digd_entry(void* a)
+{
+    DigArgs* A = (DigArgs*)a;
+    u32 r = zsa_digest_ddict(A->SD, A->d->dict, A->dictSize, &A->d->dd, &A->d->T);
+    if (wv_lane() == 0) A->result = r;
+}
+extern "C" void emu_free_cdict(void* h) { EmuCDict* c = (EmuCDict*)h; if (c) { free(c->dict); free(c->table); free(c); } }
+extern "C" void emu_free_ddict(void* h) { EmuDDict* d = (EmuDDict*)h; if (d) { free(d->dict); free(d); } }
+extern "C" void* emu_create_cdict(const void* dict, size_t n, int level)
+{
+    static ZsaEncShared SE; static ZsaDecShared SD;
+    ZsaCParams cp;
+    if (zsa_resolveCParams(&cp, level, ZSA_SIZE_UNKNOWN, n, zsa_cpm_createCDict) || cp.strat != 1) return nullptr;
+    EmuCDict* c = (EmuCDict*)calloc(1, sizeof(EmuCDict));
+    c->dict = (u8*)malloc(n + 16); if (n) memcpy(c->dict, dict, n);
+    c->table = (u32*)calloc((size_t)1 << cp.hlog, 4);
+    DigArgs A = { &SE, &SD, c, nullptr, (u32)n, cp, level, 0 };
+    emu_run_wave(digc_entry, &A);
+    if (A.result) { emu_free_cdict(c); return nullptr; }
+    return c;
+}
+extern "C" void* emu_create_ddict(const void* dict, size_t n)
+{
+    static ZsaDecShared SD;
+    EmuDDict* d = (EmuDDict*)calloc(1, sizeof(EmuDDict));
+    d->dict = (u8*)malloc(n + 16); if (n) memcpy(d->dict, dict, n);
+    DigArgs A = { nullptr, &SD, nullptr, d, (u32)n, {}, 0, 0 };
+    emu_run_wave(digd_entry, &A);
+    if (A.result) { emu_free_ddict(d); return nullptr; }
+    return d;
+}
+extern "C" size_t emu_compress_cdict(void* dst, size_t cap, const void* src, size_t n, const void* h)
+{
+    static ZsaEncShared S;
+    static u32* ht = (u32*)malloc(sizeof(u32) << 17);
+    static u64* seq = (u64*)malloc(8 * (32768 + 64));
+    static u8* lit = (u8*)malloc(ZSA_BLOCKSIZE_MAX + 128);
+    static u8* tmp = (u8*)malloc(ZSA_BLOCKSIZE_MAX * 2 + 512);
+    static const u8 empty[16] = {0};
+    const EmuCDict* c = (const EmuCDict*)h;
+    ZsaCParams cp; int mode = 0;
+    if (zsa_resolveCDictUse(&cp, &mode, c->cd.cp, c->cd.level, c->cd.dictSize, n) || cp.strat != 1 || cp.hlog > 17) return (size_t)ZSA_ERR(ZSA_parameter_unsupported);
+    EncArgs A = { &S, ht, { cp.wlog, cp.hlog, cp.mml, cp.tlen }, n ? (const u8*)src : empty + 8, n, (u8*)dst, cap, { seq, lit, tmp }, &c->cd, mode, 0 };
+    emu_run_wave(enc_entry, &A);
+    return (size_t)A.result;
+}
+extern "C" size_t emu_decompress_ddict(void* dst, size_t cap, const void* src, size_t n, const void* h)
+{
+    static ZsaDecShared S;
+    static u8* litBuf = (u8*)malloc(ZSA_BLOCKSIZE_MAX + 64);
+    DecArgs A = { &S, (const u8*)src, n, (u8*)dst, cap, litBuf, &((const EmuDDict*)h)->dd, 0 };
+    emu_run_wave(dec_entry, &A);
     return (size_t)A.result;
 }
 #endif

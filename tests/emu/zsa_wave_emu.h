@@ -65,6 +65,7 @@ ZSA_DEV void wv_sync() { (void)emu_collect(0); }
 ZSA_DEV unsigned long long wv_clock() { return 0; }
 ZSA_DEV unsigned wv_atomic_add_lds(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 ZSA_DEV unsigned wv_atomic_or_lds(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
+ZSA_DEV unsigned wv_atomic_max_lds(unsigned* p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
 ZSA_DEV unsigned wv_atomic_add_global(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 
 ZSA_DEV unsigned wv_scan_incl(unsigned v)

@@ -17,3 +17,40 @@ def small_inputs():
     return cases
 
 
+# ---- dictionary path (BulkProcessor, zstd_bulk.go) ----
+# The 256-byte dictionary is DATA held by the reference's own test (zstd_bullk_test.go:12-17).
+REF_TEST_DICT_B64 = (
+    "N6Qw7IsuFDIdENCSQjr//////4+QlekuNkmXbUBIkIDiVRX7H4AzAFCgQCFCO9oHAAAEQEuSikaK"
+    "Dg51OYghBYgBAAAAAAAAAAAAAAAAAAAAANQVpmRQGQAAAAAAAAAAAAAAAAABAAAABAAAAAgAAABo"
+    "ZWxwIEpvaW4gZW5naW5lZXJzIGVuZ2luZWVycyBmdXR1cmUgbG92ZSB0aGF0IGFyZWlsZGluZyB1"
+    "c2UgaGVscCBoZWxwIHVzaGVyIEpvaW4gdXNlIGxvdmUgdXMgSm9pbiB1bmQgaW4gdXNoZXIgdXNo"
+    "ZXIgYSBwbGF0Zm9ybSB1c2UgYW5kIGZ1dHVyZQ==")
+REF_TEST_PAYLOAD = b"We're building a platform that engineers love to use. Join us, and help usher in the future."   # zstd_bullk_test.go:31
+
+
+def dict_payloads(corpus):
+    """Deterministic payloads for the dictionary tests: (name, bytes).  Sizes straddle the reference's three ways of
+    bringing a CDict in (attach <= 8 KiB < copy < 128 KiB <= reload, zstd_compress.c:2254-2267, 5017-5025)."""
+    rnd = random.Random(20260102)
+    words = ["We", "are", "building", "a platform", "that", "engineers", "love", "to", "use", "Join", "us", "and", "help",
+             "usher", "in", "the", "future"]   # zstd_bullk_test.go:46
+    out = [("empty", b""), ("a", b"a"), ("ref_payload", REF_TEST_PAYLOAD)]
+    for i in range(6):
+        out.append(("words%d" % i, " ".join(rnd.choice(words) for _ in range(10 + rnd.randrange(100))).encode()))
+    log = corpus.generate("log", 300 * 1024, 1, 77).tobytes()
+    js = corpus.generate("json", 1024, 24, 78).tobytes()
+    for n in (7, 8, 9, 64, 200, 1000, 4000, 8192, 8193, 20000, 65536, 131071, 131072, 140000, 270000):
+        out.append(("log77_%d" % n, log[:n]))
+    for i in range(0, 24, 3):
+        out.append(("json78_1k_%d" % i, js[i * 1024:(i + 1) * 1024]))
+    out.append(("rand5000", rnd.randbytes(5000)))
+    out.append(("zeros50k", bytes(50000)))
+    return out
+
+
+def raw_dicts(corpus):
+    """Raw-content dictionaries (no entropy header), named."""
+    log = corpus.generate("log", 4096, 28, 5).tobytes()
+    js = corpus.generate("json", 4096, 10, 9).tobytes()
+    return [("raw_7", b"abcdefg"), ("raw_9", b"abcdefghi"), ("raw_log_4k", log[1000:5096]), ("raw_json_40k", js[:40000]),
+            ("raw_log_112k", log[:112 * 1024])]

@@ -23,6 +23,12 @@ def emu():
     lib.emu_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t] + [ctypes.c_uint] * 4
     lib.emu_decompress.restype = ctypes.c_size_t
     lib.emu_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    V, S = ctypes.c_void_p, ctypes.c_size_t
+    lib.emu_create_cdict.restype = V; lib.emu_create_cdict.argtypes = [ctypes.c_char_p, S, ctypes.c_int]
+    lib.emu_create_ddict.restype = V; lib.emu_create_ddict.argtypes = [ctypes.c_char_p, S]
+    lib.emu_compress_cdict.restype = S; lib.emu_compress_cdict.argtypes = [V, S, ctypes.c_char_p, S, V]
+    lib.emu_decompress_ddict.restype = S; lib.emu_decompress_ddict.argtypes = [V, S, ctypes.c_char_p, S, V]
+    lib.emu_free_cdict.argtypes = [V]; lib.emu_free_ddict.argtypes = [V]
     return lib
 
 
@@ -57,3 +63,34 @@ def test_emulated_decoder_errors(emu, oracle):
         m = emu.emu_decompress(out, cap, x, len(x))
         want = oracle.decompress(x, cap)
         assert isinstance(want, int) and m == 2 ** 64 + want, (len(x), cap, m, want)
+
+
+def test_emulated_dictionary_path_matches_golden(emu):
+    """digest kernels (zsa_dict.h) + attached / copied / re-loaded dictionary parses, against the reference-generated
+    fixture (tests/golden/dict_cases.json)"""
+    import hashlib
+    from test_oracle_dict import load_dict_cases
+    dicts, payloads, cases = load_dict_cases()
+    handles = {}
+    for c in cases:
+        if c["level"] != 1 and c["dict"] not in ("ref_test_dict", "raw_log_4k"):
+            continue
+        key = (c["dict"], c["level"])
+        if key not in handles:
+            d = dicts[c["dict"]]
+            handles[key] = (emu.emu_create_cdict(d, len(d), c["level"]), emu.emu_create_ddict(d, len(d)))
+            assert handles[key][0] and handles[key][1], key
+        cd, dd = handles[key]
+        p = payloads[c["payload"]]
+        cap = zstd_amd.CompressBound(len(p))
+        buf = ctypes.create_string_buffer(cap + 1)
+        n = emu.emu_compress_cdict(buf, cap, p, len(p), cd)
+        assert n == c["c_len"] and hashlib.sha256(buf.raw[:n]).hexdigest()[:32] == c["c_sha256"], (c["dict"], c["level"], c["payload"])
+        out = ctypes.create_string_buffer(len(p) + 1)
+        m = emu.emu_decompress_ddict(out, len(p), buf.raw[:n], n, dd)
+        assert m == len(p) and out.raw[:m] == p
+    for cd, dd in handles.values():
+        emu.emu_free_cdict(cd); emu.emu_free_ddict(dd)
+    bad = dicts["ref_test_dict"]
+    bad = bad[:40] + bytes([bad[40] ^ 0xFF]) + bad[41:60]
+    assert not emu.emu_create_cdict(bad, len(bad), 1) and not emu.emu_create_ddict(bad, len(bad))

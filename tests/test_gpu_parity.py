@@ -200,3 +200,77 @@ def test_full_size_round_trip_properties(z):
     before = cbuf.clone()
     enc.compress(1)
     assert enc.results() == cs and bool(torch.equal(before, cbuf))
+
+
+def test_bulk_processor_matches_golden(z):
+    """BulkProcessor (zstd_bulk.go): CDict/DDict digested on the device; every reference-generated case of
+    tests/golden/dict_cases.json byte-identical, in one batch launch per dictionary and through the single-call ABI."""
+    from test_oracle_dict import load_dict_cases
+    dicts, payloads, cases = load_dict_cases()
+    groups = {}
+    for c in cases:
+        groups.setdefault((c["dict"], c["level"]), []).append(c)
+    for (dn, level), cs in groups.items():
+        bp = z.NewBulkProcessor(dicts[dn], level)
+        srcs = [payloads[c["payload"]] for c in cs]
+        got = bp.CompressBatch(srcs)
+        for c, g in zip(cs, got):
+            assert isinstance(g, bytes), (dn, level, c["payload"], g)
+            assert len(g) == c["c_len"] and hashlib.sha256(g).hexdigest()[:32] == c["c_sha256"], (dn, level, c["payload"])
+        assert bp.DecompressBatch(got, [max(len(s), 1) for s in srcs]) == srcs
+        one = bp.Compress(None, srcs[2])
+        assert one == got[2] and bp.Decompress(None, one) == srcs[2]
+
+
+def test_bulk_processor_go_cases(z, oracle):
+    # zstd_bullk_test.go:62-81, 83-99, 101-126, 182-199, 227-250
+    import base64
+    from golden_inputs import REF_TEST_DICT_B64, REF_TEST_PAYLOAD
+    d = base64.b64decode(REF_TEST_DICT_B64)
+    bp = z.NewBulkProcessor(d, z.BestSpeed)
+    rnd = random.Random(3)
+    words = ["We", "are", "building", "a platform", "that", "engineers", "love", "to", "use", "Join", "us", "and", "help", "usher", "in", "the", "future"]
+    texts = [" ".join(rnd.choice(words) for _ in range(10 + rnd.randrange(100))).encode() for _ in range(100)]
+    comp = bp.CompressBatch(texts)
+    cd = oracle.cdict(d, 1)
+    for t, c in zip(texts, comp):
+        assert c == oracle.compress_cdict(t, cd)
+    assert bp.DecompressBatch(list(reversed(comp))) == list(reversed(texts))        # :201-225
+    for bad in (b"", None):
+        with pytest.raises(z.api.ZstdError):
+            z.NewBulkProcessor(bad if bad is not None else b"", z.BestSpeed)        # ErrEmptyDictionary
+    e = bp.Compress(None, b"")
+    assert len(e) >= 4 and bp.Decompress(None, e) == b""
+    with pytest.raises(z.api.ZstdError):
+        bp.Decompress(None, b"")                                                    # ErrEmptySlice
+    c = bp.Compress(None, REF_TEST_PAYLOAD)
+    assert c == oracle.compress_cdict(REF_TEST_PAYLOAD, cd)
+    # a frame that names a dictionary fails without it / with another one, like the reference
+    r = z.DecompressBatch([c], [200])[0]
+    assert isinstance(r, z.ErrorCode) and r.code == oracle.decompress(c, 200)
+    other = z.NewBulkProcessor(d[:4] + (77).to_bytes(4, "little") + d[8:], 1)
+    r = other.DecompressBatch([c], [200])[0]
+    assert isinstance(r, z.ErrorCode) and r.code == -32
+    # corrupted dictionary -> ErrBadDictionary (zstd_bulk.go:44-46)
+    with pytest.raises(z.api.ZstdError):
+        z.NewBulkProcessor(d[:40] + bytes([d[40] ^ 0xFF]) + d[41:60], 1)
+    # highly compressible frame made without the dictionary decodes through the DDict path when dst is given (:227-250)
+    big = z.CompressLevel(None, bytes(1000 * 1000), 1)
+    assert bp.DecompressBatch([big], [1000 * 1000])[0] == bytes(1000 * 1000)
+
+
+def test_bulk_small_payload_batch(z, oracle):
+    # BASELINE configs[2] shape at test size: 1 KiB JSON payloads with a trained dictionary, one launch
+    from test_oracle_dict import load_dict_cases
+    from zstd_amd import corpus
+    dicts, _, _ = load_dict_cases()
+    d = dicts["trained_json_8k"]
+    bp = z.NewBulkProcessor(d, 1)
+    frames = corpus.frames("json", 1024, 4096, 4242)
+    got = bp.CompressBatch(frames)
+    cd = oracle.cdict(d, 1)
+    for i in range(0, 4096, 37):
+        assert got[i] == oracle.compress_cdict(frames[i], cd)
+    assert all(isinstance(g, bytes) for g in got)
+    assert bp.DecompressBatch(got, [1024] * len(frames)) == frames
+    assert sum(map(len, got)) < 0.45 * 1024 * 4096

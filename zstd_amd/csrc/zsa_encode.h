@@ -19,16 +19,21 @@
 // Serial sections run under `lane == 0` and publish through LDS; every wv_* call is reached by all lanes.
 #pragma once
 #include "zsa_common.h"
+#include "zsa_params.h"
 
 struct ZsaEncParams { u32 wlog, hlog, mml, tlen; };
 
 struct ZsaHufCT { u8 nbBits[256]; u16 val[256]; };
 struct ZsaFseCT { u16 nextState[512]; s32 dfs[ZSA_MaxSeq + 1]; u32 dnb[ZSA_MaxSeq + 1]; u32 tableLog; };
 
-struct ZsaCDictDev {            // digested compression dictionary, device resident
-    const u8* content; u32 contentSize; u32 dictID;
-    u32 hlog, mml;              // CDict cParams (cpm_createCDict)
-    const u32* hashTable;       // tagged: (index << 8) | tag
+struct ZsaCDictDev {            // digested compression dictionary, device resident (zstd_compress.c ZSTD_CDict_s)
+    const u8* content; u32 contentSize;   // the part of the dictionary that entered the window (after the entropy header)
+    u32 dictSize;               // size of the whole dictionary (cdict->dictContentSize)
+    u32 isLoaded;               // 0: dictionary ignored (< 8 bytes)
+    u32 dictID;
+    s32 level;                  // cdict->compressionLevel
+    ZsaCParams cp;              // cpm_createCDict parameters
+    const u32* hashTable;       // tagged: (index << 8) | tag, 1 << cp.hlog entries
     u32 rep[3];
     u32 hufRepeat, llRepeat, ofRepeat, mlRepeat;
     ZsaHufCT huf;
@@ -112,15 +117,15 @@ ZSA_DEV u32 zsa_count(const u8* pIn, const u8* pMatch, const u8* const pInLimit)
 // ------------------------------------------------------------------ parse, no dictionary (zstd_fast.c:143-403), serial
 // `base` is the window base (index i <-> base + i); the frame starts at index 2.  Appends packed sequences
 // to seqOut, returns their number; *lastLL receives the size of the trailing literal run.
-ZSA_DEV u32 zsa_parse_fast(u32* hashTable, const ZsaEncParams& P, const u8* base, u32 dictLimit,
+ZSA_DEV u32 zsa_parse_fast(u32* hashTable, const ZsaEncParams& P, const u8* base, u32 dictLimit, u32 loadedDictEnd,
                            const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL)
 {
     u32 const hlog = P.hlog, mls = P.mml;
     u32 const stepSize = (P.tlen > 1) ? (P.tlen + 1) : 2;      // zstd_fast.c:153, :429
     const u8* const istart = src;
     u32 const endIndex = (u32)(istart - base) + srcSize;
-    u32 const maxDistance = 1u << P.wlog;
-    // ZSTD_getLowestPrefixIndex (zstd_compress_internal.h:1307-1318), no loaded dictionary
+    u32 const maxDistance = loadedDictEnd ? 0xFFFFFFFFu : 1u << P.wlog;
+    // ZSTD_getLowestPrefixIndex (zstd_compress_internal.h:1307-1318): with a loaded dictionary the whole prefix is valid
     u32 const prefixStartIndex = (endIndex - dictLimit > maxDistance) ? endIndex - maxDistance : dictLimit;
     const u8* const prefixStart = base + prefixStartIndex;
     const u8* const iend = istart + srcSize;
@@ -220,6 +225,281 @@ ZSA_DEV u32 zsa_parse_fast(u32* hashTable, const ZsaEncParams& P, const u8* base
     saved2 = ((saved1 != 0) && (rep1 != 0)) ? saved1 : saved2;
     rep[0] = rep1 ? rep1 : saved1;
     rep[1] = rep2 ? rep2 : saved2;
+    *lastLL = (u32)(iend - anchor);
+    return nbSeq;
+}
+
+// zstd_compress_internal.h:780-793 ZSTD_count_2segments
+ZSA_DEV u32 zsa_count_2segments(const u8* ip, const u8* match, const u8* iEnd, const u8* mEnd, const u8* iStart)
+{
+    const u8* const vEnd = (ip + (mEnd - match) < iEnd) ? ip + (mEnd - match) : iEnd;
+    u32 const matchLength = zsa_count(ip, match, vEnd);
+    if (match + matchLength != mEnd) return matchLength;
+    return matchLength + zsa_count(ip + matchLength, iStart, iEnd);
+}
+
+// window of one frame (zstd_compress_internal.h ZSTD_window_t + the match-state fields the fast parsers read)
+struct ZsaWindow {
+    const u8* base;       // index i of the current segment <-> base + i
+    const u8* dictBase;   // indices in [lowLimit, dictLimit) <-> dictBase + i (extDict)
+    u32 dictLimit, lowLimit, loadedDictEnd;
+    const ZsaCDictDev* dms;   // attached dictionary, or null
+};
+
+// ------------------------------------------------------------------ parse, attached dictionary (zstd_fast.c:459-656), serial
+ZSA_DEV u32 zsa_parse_fast_dms(u32* hashTable, const ZsaEncParams& P, const ZsaWindow& Wn,
+                               const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL)
+{
+    u32 const hlog = P.hlog, mls = P.mml;
+    u32 const stepSize = P.tlen + !P.tlen;
+    const u8* const base = Wn.base;
+    const u8* const istart = src;
+    const u8* ip0 = istart;
+    const u8* ip1 = ip0 + stepSize;
+    const u8* anchor = istart;
+    u32 const prefixStartIndex = Wn.dictLimit;
+    const u8* const prefixStart = base + prefixStartIndex;
+    const u8* const iend = istart + srcSize;
+    const u8* const ilimit = iend - 8;
+    u32 offset_1 = rep[0], offset_2 = rep[1];
+    const ZsaCDictDev* const dms = Wn.dms;
+    const u32* const dictHashTable = dms->hashTable;
+    u32 const dictStartIndex = 2;
+    const u8* const dictBase = dms->content - 2;
+    const u8* const dictStart = dictBase + dictStartIndex;
+    const u8* const dictEnd = dms->content + dms->contentSize;
+    u32 const dictIndexDelta = prefixStartIndex - (u32)(dictEnd - dictBase);
+    u32 const dictAndPrefixLength = (u32)(istart - prefixStart + dictEnd - dictStart);
+    u32 const dictHBits = dms->cp.hlog + 8;
+    u32 nbSeq = 0;
+
+    ip0 += (dictAndPrefixLength == 0);
+    while (ip1 <= ilimit) {
+        u32 mLength;
+        u32 hash0 = zsa_hash(zsa_ld64(ip0), hlog, mls);
+        u32 const dictHashAndTag0 = zsa_hash(zsa_ld64(ip0), dictHBits, mls);
+        u32 dictMatchIndexAndTag = dictHashTable[dictHashAndTag0 >> 8];
+        int dictTagsMatch = (dictMatchIndexAndTag & 0xFF) == (dictHashAndTag0 & 0xFF);
+        u32 matchIndex = hashTable[hash0];
+        u32 curr = (u32)(ip0 - base);
+        u32 step = stepSize;
+        const u8* nextStep = ip0 + 256;
+        for (;;) {
+            const u8* match = base + matchIndex;
+            u32 const repIndex = curr + 1 - offset_1;
+            const u8* repMatch = (repIndex < prefixStartIndex) ? dictBase + (repIndex - dictIndexDelta) : base + repIndex;
+            u64 const v1 = zsa_ld64(ip1);
+            u32 const hash1 = zsa_hash(v1, hlog, mls);
+            u32 const dictHashAndTag1 = zsa_hash(v1, dictHBits, mls);
+            hashTable[hash0] = curr;
+            if (((u32)((prefixStartIndex - 1) - repIndex) >= 3) && (zsa_ld32(repMatch) == zsa_ld32(ip0 + 1))) {
+                const u8* const repMatchEnd = repIndex < prefixStartIndex ? dictEnd : iend;
+                mLength = zsa_count_2segments(ip0 + 1 + 4, repMatch + 4, iend, repMatchEnd, prefixStart) + 4;
+                ip0++;
+                seqOut[nbSeq++] = zsa_packseq((u32)(ip0 - anchor), mLength - ZSA_MINMATCH, 1);
+                break;
+            }
+            if (dictTagsMatch) {
+                u32 const dictMatchIndex = dictMatchIndexAndTag >> 8;
+                const u8* dictMatch = dictBase + dictMatchIndex;
+                if (dictMatchIndex > dictStartIndex && zsa_ld32(dictMatch) == zsa_ld32(ip0)) {
+                    if (matchIndex <= prefixStartIndex) {
+                        u32 const offset = (u32)(curr - dictMatchIndex - dictIndexDelta);
+                        mLength = zsa_count_2segments(ip0 + 4, dictMatch + 4, iend, dictEnd, prefixStart) + 4;
+                        while (((ip0 > anchor) & (dictMatch > dictStart)) && (ip0[-1] == dictMatch[-1])) { ip0--; dictMatch--; mLength++; }
+                        offset_2 = offset_1;
+                        offset_1 = offset;
+                        seqOut[nbSeq++] = zsa_packseq((u32)(ip0 - anchor), mLength - ZSA_MINMATCH, offset + 3);
+                        break;
+                    }
+                }
+            }
+            if (matchIndex > prefixStartIndex && zsa_ld32(match) == zsa_ld32(ip0)) {
+                u32 const offset = (u32)(ip0 - match);
+                mLength = zsa_count(ip0 + 4, match + 4, iend) + 4;
+                while (((ip0 > anchor) & (match > prefixStart)) && (ip0[-1] == match[-1])) { ip0--; match--; mLength++; }
+                offset_2 = offset_1;
+                offset_1 = offset;
+                seqOut[nbSeq++] = zsa_packseq((u32)(ip0 - anchor), mLength - ZSA_MINMATCH, offset + 3);
+                break;
+            }
+            dictMatchIndexAndTag = dictHashTable[dictHashAndTag1 >> 8];
+            dictTagsMatch = (dictMatchIndexAndTag & 0xFF) == (dictHashAndTag1 & 0xFF);
+            matchIndex = hashTable[hash1];
+            if (ip1 >= nextStep) { step++; nextStep += 256; }
+            ip0 = ip1;
+            ip1 = ip1 + step;
+            if (ip1 > ilimit) goto cleanup;
+            curr = (u32)(ip0 - base);
+            hash0 = hash1;
+        }
+        ip0 += mLength;
+        anchor = ip0;
+        if (ip0 <= ilimit) {
+            hashTable[zsa_hash(zsa_ld64(base + curr + 2), hlog, mls)] = curr + 2;
+            hashTable[zsa_hash(zsa_ld64(ip0 - 2), hlog, mls)] = (u32)(ip0 - 2 - base);
+            while (ip0 <= ilimit) {
+                u32 const current2 = (u32)(ip0 - base);
+                u32 const repIndex2 = current2 - offset_2;
+                const u8* repMatch2 = repIndex2 < prefixStartIndex ? dictBase - dictIndexDelta + repIndex2 : base + repIndex2;
+                if (((u32)((prefixStartIndex - 1) - repIndex2) >= 3) && (zsa_ld32(repMatch2) == zsa_ld32(ip0))) {
+                    const u8* const repEnd2 = repIndex2 < prefixStartIndex ? dictEnd : iend;
+                    u32 const repLength2 = zsa_count_2segments(ip0 + 4, repMatch2 + 4, iend, repEnd2, prefixStart) + 4;
+                    { u32 const t = offset_2; offset_2 = offset_1; offset_1 = t; }
+                    seqOut[nbSeq++] = zsa_packseq(0, repLength2 - ZSA_MINMATCH, 1);
+                    hashTable[zsa_hash(zsa_ld64(ip0), hlog, mls)] = current2;
+                    ip0 += repLength2;
+                    anchor = ip0;
+                    continue;
+                }
+                break;
+            }
+        }
+        ip1 = ip0 + stepSize;
+    }
+cleanup:
+    rep[0] = offset_1;
+    rep[1] = offset_2;
+    *lastLL = (u32)(iend - anchor);
+    return nbSeq;
+}
+
+// ------------------------------------------------------------------ parse, dictionary as extDict (zstd_fast.c:685-936), serial
+// Returns 0xFFFFFFFF when the extDict has been invalidated for this block (zstd_fast.c:737-738): the caller
+// then runs the plain parser.
+ZSA_DEV u32 zsa_parse_fast_ext(u32* hashTable, const ZsaEncParams& P, const ZsaWindow& Wn,
+                               const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL)
+{
+    u32 const hlog = P.hlog, mls = P.mml;
+    u32 const stepSize = P.tlen + !P.tlen + 1;
+    const u8* const base = Wn.base;
+    const u8* const dictBase = Wn.dictBase;
+    const u8* const istart = src;
+    const u8* anchor = istart;
+    u32 const endIndex = (u32)(istart - base) + srcSize;
+    u32 lowLimit;
+    {   // ZSTD_getLowestMatchIndex (zstd_compress_internal.h:1290-1302)
+        u32 const maxDistance = 1u << P.wlog, lowestValid = Wn.lowLimit;
+        u32 const withinWindow = (endIndex - lowestValid > maxDistance) ? endIndex - maxDistance : lowestValid;
+        lowLimit = Wn.loadedDictEnd != 0 ? lowestValid : withinWindow;
+    }
+    u32 const dictStartIndex = lowLimit;
+    const u8* const dictStart = dictBase + dictStartIndex;
+    u32 const dictLimit = Wn.dictLimit;
+    u32 const prefixStartIndex = dictLimit < lowLimit ? lowLimit : dictLimit;
+    const u8* const prefixStart = base + prefixStartIndex;
+    const u8* const dictEnd = dictBase + prefixStartIndex;
+    const u8* const iend = istart + srcSize;
+    const u8* const ilimit = iend - 8;
+    u32 offset_1 = rep[0], offset_2 = rep[1], offsetSaved1 = 0, offsetSaved2 = 0;
+    const u8* ip0 = istart;
+    u32 nbSeq = 0;
+
+    if (prefixStartIndex == dictStartIndex) return 0xFFFFFFFFu;
+    {   u32 const curr = (u32)(ip0 - base);
+        u32 const maxRep = curr - dictStartIndex;
+        if (offset_2 >= maxRep) { offsetSaved2 = offset_2; offset_2 = 0; }
+        if (offset_1 >= maxRep) { offsetSaved1 = offset_1; offset_1 = 0; }
+    }
+    for (;;) {
+        u32 step = stepSize;
+        const u8* nextStep = ip0 + 128;
+        const u8* ip1 = ip0 + 1;
+        const u8* ip2 = ip0 + step;
+        const u8* ip3 = ip2 + 1;
+        u32 hash0, hash1, idx, current0 = 0, offcode = 0, mLength = 0;
+        const u8* idxBase;
+        const u8* match0 = base;
+        const u8* matchEnd = iend;
+        int found = 0;
+        if (ip3 >= ilimit) break;
+        hash0 = zsa_hash(zsa_ld64(ip0), hlog, mls);
+        hash1 = zsa_hash(zsa_ld64(ip1), hlog, mls);
+        idx = hashTable[hash0];
+        idxBase = idx < prefixStartIndex ? dictBase : base;
+        do {
+            {   u32 const current2 = (u32)(ip2 - base);
+                u32 const repIndex = current2 - offset_1;
+                const u8* const repBase = repIndex < prefixStartIndex ? dictBase : base;
+                u32 rval;
+                if (((u32)(prefixStartIndex - repIndex) >= 4) & (offset_1 > 0)) rval = zsa_ld32(repBase + repIndex);
+                else rval = zsa_ld32(ip2) ^ 1;
+                current0 = (u32)(ip0 - base);
+                hashTable[hash0] = current0;
+                if (zsa_ld32(ip2) == rval) {
+                    ip0 = ip2;
+                    match0 = repBase + repIndex;
+                    matchEnd = repIndex < prefixStartIndex ? dictEnd : iend;
+                    mLength = ip0[-1] == match0[-1];
+                    ip0 -= mLength; match0 -= mLength;
+                    offcode = 1;
+                    mLength += 4;
+                    found = 1;
+                    break;
+                }
+            }
+            {   u32 const mval = idx >= dictStartIndex ? zsa_ld32(idxBase + idx) : zsa_ld32(ip0) ^ 1;
+                if (zsa_ld32(ip0) == mval) { found = 2; break; }
+            }
+            idx = hashTable[hash1];
+            idxBase = idx < prefixStartIndex ? dictBase : base;
+            hash0 = hash1;
+            hash1 = zsa_hash(zsa_ld64(ip2), hlog, mls);
+            ip0 = ip1; ip1 = ip2; ip2 = ip3;
+            current0 = (u32)(ip0 - base);
+            hashTable[hash0] = current0;
+            {   u32 const mval = idx >= dictStartIndex ? zsa_ld32(idxBase + idx) : zsa_ld32(ip0) ^ 1;
+                if (zsa_ld32(ip0) == mval) { found = 2; break; }
+            }
+            idx = hashTable[hash1];
+            idxBase = idx < prefixStartIndex ? dictBase : base;
+            hash0 = hash1;
+            hash1 = zsa_hash(zsa_ld64(ip2), hlog, mls);
+            ip0 = ip1; ip1 = ip2;
+            ip2 = ip0 + step;
+            ip3 = ip1 + step;
+            if (ip2 >= nextStep) { step++; nextStep += 128; }
+        } while (ip3 < ilimit);
+        if (!found) break;
+        if (found == 2) {
+            u32 const offset = current0 - idx;
+            const u8* const lowMatchPtr = idx < prefixStartIndex ? dictStart : prefixStart;
+            matchEnd = idx < prefixStartIndex ? dictEnd : iend;
+            match0 = idxBase + idx;
+            offset_2 = offset_1;
+            offset_1 = offset;
+            offcode = offset + 3;
+            mLength = 4;
+            while (((ip0 > anchor) & (match0 > lowMatchPtr)) && (ip0[-1] == match0[-1])) { ip0--; match0--; mLength++; }
+        }
+        mLength += zsa_count_2segments(ip0 + mLength, match0 + mLength, iend, matchEnd, prefixStart);
+        seqOut[nbSeq++] = zsa_packseq((u32)(ip0 - anchor), mLength - ZSA_MINMATCH, offcode);
+        ip0 += mLength;
+        anchor = ip0;
+        if (ip1 < ip0) hashTable[hash1] = (u32)(ip1 - base);
+        if (ip0 <= ilimit) {
+            hashTable[zsa_hash(zsa_ld64(base + current0 + 2), hlog, mls)] = current0 + 2;
+            hashTable[zsa_hash(zsa_ld64(ip0 - 2), hlog, mls)] = (u32)(ip0 - 2 - base);
+            while (ip0 <= ilimit) {
+                u32 const repIndex2 = (u32)(ip0 - base) - offset_2;
+                const u8* const repMatch2 = repIndex2 < prefixStartIndex ? dictBase + repIndex2 : base + repIndex2;
+                if ((((u32)((prefixStartIndex - 1) - repIndex2) >= 3) & (offset_2 > 0)) && (zsa_ld32(repMatch2) == zsa_ld32(ip0))) {
+                    const u8* const repEnd2 = repIndex2 < prefixStartIndex ? dictEnd : iend;
+                    u32 const repLength2 = zsa_count_2segments(ip0 + 4, repMatch2 + 4, iend, repEnd2, prefixStart) + 4;
+                    { u32 const t = offset_2; offset_2 = offset_1; offset_1 = t; }
+                    seqOut[nbSeq++] = zsa_packseq(0, repLength2 - ZSA_MINMATCH, 1);
+                    hashTable[zsa_hash(zsa_ld64(ip0), hlog, mls)] = (u32)(ip0 - base);
+                    ip0 += repLength2;
+                    anchor = ip0;
+                    continue;
+                }
+                break;
+            }
+        }
+    }
+    offsetSaved2 = ((offsetSaved1 != 0) && (offset_1 != 0)) ? offsetSaved1 : offsetSaved2;
+    rep[0] = offset_1 ? offset_1 : offsetSaved1;
+    rep[1] = offset_2 ? offset_2 : offsetSaved2;
     *lastLL = (u32)(iend - anchor);
     return nbSeq;
 }
@@ -1067,7 +1347,7 @@ ZSA_DEV void zsa_gatherLiterals(ZsaEncShared* S, const u64* seq, u32 nbSeq, cons
 struct ZsaEncScratch { u64* seq; u8* lit; u8* tmp; };
 
 ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams& P, const u8* src, u64 srcSize64,
-                             u8* dst, u64 dstCapacity, const ZsaEncScratch& W, const ZsaCDictDev* cd)
+                             u8* dst, u64 dstCapacity, const ZsaEncScratch& W, const ZsaCDictDev* cd, int dictMode)
 {
     int const lane = wv_lane();
     if (srcSize64 > 0xE0000000ull) return ZSA_ERR(ZSA_srcSize_wrong);
@@ -1103,32 +1383,86 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
         wv_sync();
         return pos + 3;
     }
-    // per-frame state (zstd_compress.c:2045-2225, 1863-1872)
-    for (u32 i = (u32)lane; i < (1u << P.hlog); i += ZSA_WAVE) hashTable[i] = 0;
-    for (u32 i = (u32)lane; i < 256; i += ZSA_WAVE) { S->hufPrev.nbBits[i] = 0; S->hufPrev.val[i] = 0; }
+    // per-frame state (zstd_compress.c:2045-2225, 1863-1872; with a dictionary :2270-2329, :2347-2426, :5027-5044)
+    ZsaWindow Wn;
+    Wn.base = src - 2; Wn.dictBase = src - 2; Wn.dictLimit = 2; Wn.lowLimit = 2; Wn.loadedDictEnd = 0; Wn.dms = nullptr;
+    if (cd && dictMode == zsa_dm_copy) {   // ZSTD_copyCDictTableIntoCCtx: tags removed
+        for (u32 i = (u32)lane; i < (1u << P.hlog); i += ZSA_WAVE) hashTable[i] = cd->hashTable[i] >> 8;
+    } else {
+        for (u32 i = (u32)lane; i < (1u << P.hlog); i += ZSA_WAVE) hashTable[i] = 0;
+    }
+    if (cd) {
+        for (u32 i = (u32)lane; i < 256; i += ZSA_WAVE) { S->hufPrev.nbBits[i] = cd->huf.nbBits[i]; S->hufPrev.val[i] = cd->huf.val[i]; }
+    } else {
+        for (u32 i = (u32)lane; i < 256; i += ZSA_WAVE) { S->hufPrev.nbBits[i] = 0; S->hufPrev.val[i] = 0; }
+    }
     if (lane == 0) {
-        S->prevRep[0] = 1; S->prevRep[1] = 4; S->prevRep[2] = 8;
-        S->prevHufRepeat = zsa_rep_none; S->prevLL = S->prevOF = S->prevML = zsa_rep_none;
+        if (cd) {
+            S->prevRep[0] = cd->rep[0]; S->prevRep[1] = cd->rep[1]; S->prevRep[2] = cd->rep[2];
+            S->prevHufRepeat = cd->hufRepeat; S->prevLL = cd->llRepeat; S->prevOF = cd->ofRepeat; S->prevML = cd->mlRepeat;
+        } else {
+            S->prevRep[0] = 1; S->prevRep[1] = 4; S->prevRep[2] = 8;
+            S->prevHufRepeat = zsa_rep_none; S->prevLL = S->prevOF = S->prevML = zsa_rep_none;
+        }
         S->err = 0;
     }
     wv_sync();
+    if (cd) {
+        u32 const cdictEnd = 2 + cd->contentSize, cdictLen = cd->contentSize;
+        if (dictMode == zsa_dm_attach) {
+            if (cdictLen != 0) {
+                Wn.dms = cd;
+                Wn.base = src - cdictEnd; Wn.dictBase = Wn.base;
+                Wn.dictLimit = cdictEnd; Wn.lowLimit = cdictEnd; Wn.loadedDictEnd = cdictEnd;
+            }
+        } else {
+            if (dictMode == zsa_dm_load && cd->isLoaded && cdictLen > 8) {
+                // zstd_compress.c:4740-4761 + zstd_fast.c:50-82 (dtlm_fast): every third position of the indexable
+                // suffix is inserted, later positions overwrite earlier ones == the largest index wins per cell
+                u32 const m = P.hlog;   // chainLog <= hashLog in every ZSTD_fast row
+                u32 const maxDictSize = 8u << (m < 28 ? m : 28);
+                u32 const from = cdictLen > maxDictSize ? cdictEnd - maxDictSize : 2;
+                if (cdictEnd - from > 8) {
+                    const u8* const dbase = cd->content - 2;
+                    // loop bound: ip + 3 < (end - 8) + 2  <=>  index + 9 < cdictEnd
+                    for (u32 idx = from + 3 * (u32)lane; idx + 9 < cdictEnd; idx += 3 * ZSA_WAVE)
+                        wv_atomic_max_lds(&hashTable[zsa_hash(zsa_ld64(dbase + idx), P.hlog, P.mml)], idx);
+                }
+                wv_sync();
+            }
+            if (cdictLen != 0) {
+                Wn.dictBase = cd->content - 2;
+                Wn.base = src - cdictEnd;
+                Wn.lowLimit = 2; Wn.dictLimit = cdictEnd;
+                if (Wn.dictLimit - Wn.lowLimit < 8) Wn.lowLimit = Wn.dictLimit;
+            }
+            Wn.loadedDictEnd = cd->isLoaded ? cdictEnd : 0;
+        }
+    }
     u32 blockSize;
     {   u64 const ws0 = ((u64)1 << P.wlog) < srcSize ? ((u64)1 << P.wlog) : srcSize;
         blockSize = ws0 < ZSA_BLOCKSIZE_MAX ? (u32)ws0 : ZSA_BLOCKSIZE_MAX;
     }
     int const literalsDisabled = P.tlen > 0;
     u32 const maxDist = 1u << P.wlog;
-    const u8* const base = src - 2;       // first byte of the frame has index 2 (zstd_compress_internal.h:211, 1232-1285)
-    u32 dictLimit = 2;
     u32 remaining = srcSize;
     const u8* ip = src;
     int isFirstBlock = 1;
     while (remaining) {
         u32 const lastBlock = (blockSize >= remaining);
         if (remaining < blockSize) blockSize = remaining;
-        {   // ZSTD_window_enforceMaxDist (zstd_compress_internal.h:1153-1190), no dictionary
-            u32 const blockStartIdx = (u32)(ip - base);
-            if (blockStartIdx > maxDist) { u32 const nl = blockStartIdx - maxDist; if (dictLimit < nl) dictLimit = nl; }
+        {   // ZSTD_checkDictValidity (zstd_compress_internal.h:1199-1230)
+            u32 const blockEndIdx = (u32)(ip + blockSize - Wn.base);
+            if (blockEndIdx > Wn.loadedDictEnd + maxDist || Wn.loadedDictEnd != Wn.dictLimit) { Wn.loadedDictEnd = 0; Wn.dms = nullptr; }
+        }
+        {   // ZSTD_window_enforceMaxDist (zstd_compress_internal.h:1153-1190)
+            u32 const blockStartIdx = (u32)(ip - Wn.base);
+            if (blockStartIdx > maxDist + Wn.loadedDictEnd) {
+                u32 const nl = blockStartIdx - maxDist;
+                if (Wn.lowLimit < nl) Wn.lowLimit = nl;
+                if (Wn.dictLimit < Wn.lowLimit) Wn.dictLimit = Wn.lowLimit;
+                Wn.loadedDictEnd = 0; Wn.dms = nullptr;
+            }
         }
         u32 cSize = 0;
         ZSA_PROF(S, lane, 0);
@@ -1136,7 +1470,11 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
             if (lane == 0) {
                 u32 rep[3] = { S->prevRep[0], S->prevRep[1], S->prevRep[2] };
                 u32 lastLL = 0;
-                u32 const nbSeq = zsa_parse_fast(hashTable, P, base, dictLimit, ip, blockSize, rep, W.seq, &lastLL);
+                u32 nbSeq = 0xFFFFFFFFu;   // zstd_compress_internal.h:971-978 ZSTD_matchState_dictMode
+                if (Wn.lowLimit < Wn.dictLimit) nbSeq = zsa_parse_fast_ext(hashTable, P, Wn, ip, blockSize, rep, W.seq, &lastLL);
+                else if (Wn.dms) nbSeq = zsa_parse_fast_dms(hashTable, P, Wn, ip, blockSize, rep, W.seq, &lastLL);
+                if (nbSeq == 0xFFFFFFFFu)
+                    nbSeq = zsa_parse_fast(hashTable, P, Wn.base, Wn.dictLimit, Wn.loadedDictEnd, ip, blockSize, rep, W.seq, &lastLL);
                 S->nextRep[0] = rep[0]; S->nextRep[1] = rep[1]; S->nextRep[2] = rep[2];
                 S->u[EU_nbSeq] = nbSeq; S->u[EU_lastLL] = lastLL;
             }

@@ -10,6 +10,7 @@
 #include "zsa_params.h"
 #include "zsa_decode.h"
 #include "zsa_encode.h"
+#include "zsa_dict.h"
 #include "../../include/zstd_amd.h"
 
 // ------------------------------------------------------------------------------------------------ kernels
@@ -48,7 +49,7 @@ zsa_k_decompress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ resu
 
 __global__ void __launch_bounds__(64, 2)
 zsa_k_compress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
-               u32* __restrict__ counter, u8* __restrict__ scratch, int level, const ZsaCDictDev* cd, u64* __restrict__ prof)
+               u32* __restrict__ counter, u8* __restrict__ scratch, int level, u32 maxHlog, const ZsaCDictDev* cd, u64* __restrict__ prof)
 {
     extern __shared__ __align__(16) u32 zsa_hashTable[];
     __shared__ ZsaEncShared S;
@@ -67,10 +68,13 @@ zsa_k_compress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ result
         ZSA_PROF(&S, threadIdx.x, 11);
         ZsaCParams cp;
         u64 r;
-        if (zsa_resolveCParams(&cp, level, d.srcSize, 0, zsa_cpm_noAttachDict) || cp.strat != 1) r = ZSA_ERR(ZSA_parameter_unsupported);
+        int dictMode = zsa_dm_none;
+        int const bad = cd ? zsa_resolveCDictUse(&cp, &dictMode, cd->cp, cd->level, cd->dictSize, d.srcSize)
+                           : zsa_resolveCParams(&cp, level, d.srcSize, 0, zsa_cpm_noAttachDict);
+        if (bad || cp.strat != 1 || cp.hlog > maxHlog) r = ZSA_ERR(ZSA_parameter_unsupported);
         else {
             ZsaEncParams P; P.wlog = cp.wlog; P.hlog = cp.hlog; P.mml = cp.mml; P.tlen = cp.tlen;
-            r = zsa_encode_frame(&S, zsa_hashTable, P, d.src, d.srcSize, d.dst, d.dstCapacity, W, cd);
+            r = zsa_encode_frame(&S, zsa_hashTable, P, d.src, d.srcSize, d.dst, d.dstCapacity, W, cd, dictMode);
         }
         if (threadIdx.x == 0) results[f] = r;
         __syncthreads();
@@ -190,6 +194,9 @@ extern "C" unsigned long long zsa_getFrameContentSize(const void* srcv, size_t s
     }
 }
 
+// ---- dictionaries (device-resident digests)
+#include "zsa_dict.inc"
+
 // ---- batch object
 extern "C" void zsa_batch_free(zsa_batch* b)
 {
@@ -277,16 +284,18 @@ extern "C" size_t zsa_compress_enqueue(zsa_batch* b, int level, const zsa_CDict*
 {
     if (!b) return kErrGeneric;
     if (b->nFrames == 0) return 0;
-    if (cdict) return (size_t)ZSA_ERR(ZSA_parameter_unsupported);
-    // LDS: hash table of the largest frame in the batch (hashLog depends on the size class)
+    // LDS: hash table of the largest frame in the batch (hashLog depends on the size class, and with a dictionary on
+    // how the dictionary is brought in).  Frames whose table cannot fit report "Unsupported parameter" individually.
     u32 maxHlog = 6;
     {   // hashLog is not monotone in srcSize across size classes: take the max over the classes present
         for (size_t i = 0; i < b->nFrames; i++) {
-            ZsaCParams cp;
-            if (zsa_resolveCParams(&cp, level, b->h_frames[i].srcSize, 0, zsa_cpm_noAttachDict) == 0 && cp.strat == 1 && cp.hlog > maxHlog) maxHlog = cp.hlog;
+            ZsaCParams cp; int mode = 0;
+            int const bad = cdict ? zsa_resolveCDictUse(&cp, &mode, cdict->cp, cdict->level, cdict->dictSize, b->h_frames[i].srcSize)
+                                  : zsa_resolveCParams(&cp, level, b->h_frames[i].srcSize, 0, zsa_cpm_noAttachDict);
+            if (!bad && cp.strat == 1 && cp.hlog > maxHlog) maxHlog = cp.hlog;
         }
     }
-    if (maxHlog > 15) return (size_t)ZSA_ERR(ZSA_parameter_unsupported);
+    if (maxHlog > 15) maxHlog = 15;
     size_t const dynLds = (size_t)4 << maxHlog;
     size_t const ldsPerWG = dynLds + sizeof(ZsaEncShared) + 64;
     static std::once_flag once;
@@ -294,7 +303,8 @@ extern "C" size_t zsa_compress_enqueue(zsa_batch* b, int level, const zsa_CDict*
     unsigned const grid = zsa_grid(b, ldsPerWG);
     HIPCHK(hipMemsetAsync(b->d_counter, 0, 256, (hipStream_t)stream));
     hipLaunchKernelGGL(zsa_k_compress, dim3(grid), dim3(64), dynLds, (hipStream_t)stream,
-                       b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter, b->d_scratch, level, (const ZsaCDictDev*)nullptr, b->profOn ? b->d_prof : (u64*)nullptr);
+                       b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter, b->d_scratch, level, maxHlog,
+                       cdict ? (const ZsaCDictDev*)cdict->d_cd : (const ZsaCDictDev*)nullptr, b->profOn ? b->d_prof : (u64*)nullptr);
     HIPCHK(hipGetLastError());
     b->lastWG = grid; b->lastLDS = (unsigned)ldsPerWG;
     return 0;
@@ -303,12 +313,12 @@ extern "C" size_t zsa_decompress_enqueue(zsa_batch* b, const zsa_DDict* ddict, v
 {
     if (!b) return kErrGeneric;
     if (b->nFrames == 0) return 0;
-    if (ddict) return (size_t)ZSA_ERR(ZSA_parameter_unsupported);
     size_t const ldsPerWG = sizeof(ZsaDecShared) + 64;
     unsigned const grid = zsa_grid(b, ldsPerWG);
     HIPCHK(hipMemsetAsync(b->d_counter, 0, 256, (hipStream_t)stream));
     hipLaunchKernelGGL(zsa_k_decompress, dim3(grid), dim3(64), 0, (hipStream_t)stream,
-                       b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter, b->d_scratch, (const ZsaDDictDev*)nullptr, b->profOn ? b->d_prof : (u64*)nullptr);
+                       b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter, b->d_scratch,
+                       ddict ? (const ZsaDDictDev*)ddict->d_dd : (const ZsaDDictDev*)nullptr, b->profOn ? b->d_prof : (u64*)nullptr);
     HIPCHK(hipGetLastError());
     b->lastWG = grid; b->lastLDS = (unsigned)ldsPerWG;
     return 0;
@@ -424,5 +434,3 @@ extern "C" size_t zsa_decompress(void* dst, size_t dstCapacity, const void* src,
     return e ? e : out;
 }
 
-// ---- dictionaries (device-resident digests) -- see zsa_dict.inc
-#include "zsa_dict.inc"

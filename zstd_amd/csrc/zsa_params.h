@@ -5,7 +5,7 @@
 #include "zsa_common.h"
 
 struct ZsaCParams { u32 wlog, clog, hlog, slog, mml, tlen, strat; };
-enum { zsa_cpm_noAttachDict = 0, zsa_cpm_attachDict = 1, zsa_cpm_createCDict = 2 };
+enum { zsa_cpm_noAttachDict = 0, zsa_cpm_attachDict = 1, zsa_cpm_createCDict = 2, zsa_cpm_unknown = 3 };
 #define ZSA_SIZE_UNKNOWN (~(u64)0)
 
 ZSA_HD u32 zsa_hb32(u32 v) { return 31u - (u32)__builtin_clz(v); }
@@ -22,22 +22,9 @@ ZSA_HD ZsaCParams zsa_levelRow(u32 tableID, u32 row)
     c.mml = t[tableID][row][4]; c.tlen = t[tableID][row][5]; c.strat = t[tableID][row][6];
     return c;
 }
-// returns 0 ok, 1 level outside the table
-ZSA_HD int zsa_resolveCParams(ZsaCParams* out, int level, u64 srcSizeHint, u64 dictSize, int mode)
+// zstd_compress.c:1427-1555 ZSTD_dictAndWindowLog + ZSTD_adjustCParams_internal (strategies fast/dfast)
+ZSA_HD ZsaCParams zsa_adjustCParams(ZsaCParams cp, u64 srcSize, u64 dictSize, int mode)
 {
-    u64 rSize;
-    {   u64 const ds = (mode == zsa_cpm_attachDict) ? 0 : dictSize;
-        int const unknown = srcSizeHint == ZSA_SIZE_UNKNOWN;
-        u64 const addedSize = unknown && ds > 0 ? 500 : 0;
-        rSize = unknown && ds == 0 ? ZSA_SIZE_UNKNOWN : srcSizeHint + ds + addedSize;
-    }
-    u32 const tableID = (rSize <= 256 * 1024) + (rSize <= 128 * 1024) + (rSize <= 16 * 1024);
-    u32 row;
-    if (level == 0) row = 3; else if (level < 0) row = 0; else if (level > 3) return 1; else row = (u32)level;
-    ZsaCParams cp = zsa_levelRow(tableID, row);
-    if (level < 0) { int const minLevel = -(1 << 17); int const cl = level < minLevel ? minLevel : level; cp.tlen = (u32)(-cl); }
-    // ZSTD_adjustCParams_internal
-    u64 srcSize = srcSizeHint;
     if (mode == zsa_cpm_createCDict) { if (dictSize && srcSize == ZSA_SIZE_UNKNOWN) srcSize = 513; }
     else if (mode == zsa_cpm_attachDict) dictSize = 0;
     u64 const maxWindowResize = (u64)1 << (ZSA_WLOG_MAX - 1);
@@ -58,10 +45,49 @@ ZSA_HD int zsa_resolveCParams(ZsaCParams* out, int level, u64 srcSizeHint, u64 d
         if (cp.clog > dawLog) cp.clog -= (cp.clog - dawLog);
     }
     if (cp.wlog < ZSA_WLOG_ABSMIN) cp.wlog = ZSA_WLOG_ABSMIN;
-    if (mode == zsa_cpm_createCDict && (cp.strat == 1 || cp.strat == 2)) {
+    if (mode == zsa_cpm_createCDict && (cp.strat == 1 || cp.strat == 2)) {   // ZSTD_CDictIndicesAreTagged
         if (cp.hlog > 24) cp.hlog = 24;
         if (cp.clog > 24) cp.clog = 24;
     }
+    return cp;
+}
+// zstd_compress.c:6935-6983 ZSTD_getCParams_internal.  Returns 0 ok, 1 level outside the table.
+ZSA_HD int zsa_resolveCParams(ZsaCParams* out, int level, u64 srcSizeHint, u64 dictSize, int mode)
+{
+    u64 rSize;
+    {   u64 const ds = (mode == zsa_cpm_attachDict) ? 0 : dictSize;
+        int const unknown = srcSizeHint == ZSA_SIZE_UNKNOWN;
+        u64 const addedSize = unknown && ds > 0 ? 500 : 0;
+        rSize = unknown && ds == 0 ? ZSA_SIZE_UNKNOWN : srcSizeHint + ds + addedSize;
+    }
+    u32 const tableID = (rSize <= 256 * 1024) + (rSize <= 128 * 1024) + (rSize <= 16 * 1024);
+    u32 row;
+    if (level == 0) row = 3; else if (level < 0) row = 0; else if (level > 3) return 1; else row = (u32)level;
+    ZsaCParams cp = zsa_levelRow(tableID, row);
+    if (level < 0) { int const minLevel = -(1 << 17); int const cl = level < minLevel ? minLevel : level; cp.tlen = (u32)(-cl); }
+    *out = zsa_adjustCParams(cp, srcSizeHint, dictSize, mode);
+    return 0;
+}
+// How ZSTD_compress_usingCDict brings a digested dictionary into one frame, and with which parameters:
+// zstd_compress.c:5584-5619 (parameters), :5001-5046 (cdict tables vs re-load), :2254-2267 (attach vs copy, ZSTD_fast).
+enum { zsa_dm_none = 0, zsa_dm_attach = 1, zsa_dm_copy = 2, zsa_dm_load = 3 };
+ZSA_HD int zsa_resolveCDictUse(ZsaCParams* out, int* dictMode, const ZsaCParams& cdictCp, int cdictLevel, u64 dictSize, u64 srcSize)
+{
+    bool const useCDictParams = (srcSize < 128 * 1024) || (srcSize < dictSize * 6) || (cdictLevel == 0);
+    ZsaCParams cp = cdictCp;
+    if (!useCDictParams && zsa_resolveCParams(&cp, cdictLevel, srcSize, dictSize, zsa_cpm_unknown)) return 1;
+    {   u32 const limitedSrcSize = (u32)(srcSize < (1u << 19) ? srcSize : (1u << 19));
+        u32 const limitedSrcLog = limitedSrcSize > 1 ? zsa_hb32(limitedSrcSize - 1) + 1 : 1;
+        if (cp.wlog < limitedSrcLog) cp.wlog = limitedSrcLog;
+    }
+    if (dictSize > 0 && useCDictParams) {
+        if (srcSize <= 8 * 1024) {
+            u32 const windowLog = cp.wlog;
+            cp = zsa_adjustCParams(cdictCp, srcSize, dictSize, zsa_cpm_attachDict);
+            cp.wlog = windowLog;
+            *dictMode = zsa_dm_attach;
+        } else *dictMode = zsa_dm_copy;
+    } else *dictMode = zsa_dm_load;
     *out = cp;
     return 0;
 }

@@ -20,6 +20,7 @@ ZSA_DEV void wv_sync() { __syncthreads(); }
 ZSA_DEV unsigned long long wv_clock() { return (unsigned long long)clock64(); }
 ZSA_DEV unsigned wv_atomic_add_lds(unsigned* p, unsigned v) { return atomicAdd(p, v); }
 ZSA_DEV unsigned wv_atomic_or_lds(unsigned* p, unsigned v) { return atomicOr(p, v); }
+ZSA_DEV unsigned wv_atomic_max_lds(unsigned* p, unsigned v) { return atomicMax(p, v); }
 ZSA_DEV unsigned wv_atomic_add_global(unsigned* p, unsigned v) { return atomicAdd(p, v); }
 
 // inclusive prefix sum over the 64 lanes
