@@ -13,6 +13,11 @@
 #include <string.h>
 
 ZsaEmu g_emu;
+void emu_divergence(int lineA, int lineB, int lane)
+{
+    fprintf(stderr, "emulator: divergent wave primitive: some lanes at source line %d, lane %d at line %d\n", lineA, lane, lineB);
+    abort();
+}
 static emu_kernel_fn g_fn; static void* g_arg;
 static void lane_entry()
 {

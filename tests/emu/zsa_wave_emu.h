@@ -26,6 +26,7 @@ struct ZsaEmu {
     int ndone;
     // rendezvous
     uint64_t vals[2][64];
+    int site[2];             // call-site line of the rendezvous in flight (divergence check)
     int arrived;
     unsigned gen;
 };
@@ -40,10 +41,14 @@ static inline void emu_yield()
     swapcontext(&g_emu.lane_ctx[from], &g_emu.lane_ctx[next]);
 }
 // all lanes contribute v; returns pointer to the 64 collected values (valid until the next-but-one rendezvous)
-static inline const uint64_t* emu_collect(uint64_t v)
+void emu_divergence(int lineA, int lineB, int lane);
+static inline const uint64_t* emu_collect(uint64_t v, int line)
 {
     unsigned mygen = g_emu.gen;
     uint64_t* slot = g_emu.vals[mygen & 1];
+    // every wave primitive must be reached by all lanes from the same source line: catches divergent control flow
+    if (g_emu.arrived == 0) g_emu.site[mygen & 1] = line;
+    else if (g_emu.site[mygen & 1] != line) emu_divergence(g_emu.site[mygen & 1], line, g_emu.cur);
     slot[g_emu.cur] = v;
     if (++g_emu.arrived == 64 - g_emu.ndone) { g_emu.arrived = 0; g_emu.gen++; }
     else while (g_emu.gen == mygen) emu_yield();
@@ -51,31 +56,36 @@ static inline const uint64_t* emu_collect(uint64_t v)
 }
 
 ZSA_DEV int wv_lane() { return g_emu.cur; }
-ZSA_DEV unsigned long long wv_ballot(bool p)
+ZSA_DEV unsigned long long wv_ballot(bool p, int line = __builtin_LINE())
 {
-    const uint64_t* a = emu_collect(p ? 1 : 0);
+    const uint64_t* a = emu_collect(p ? 1 : 0, line);
     unsigned long long m = 0;
     for (int i = 0; i < 64; i++) if (a[i]) m |= 1ull << i;
     return m;
 }
-ZSA_DEV unsigned wv_shfl(unsigned v, int srcLane) { const uint64_t* a = emu_collect(v); return (unsigned)a[srcLane & 63]; }
-ZSA_DEV unsigned wv_shfl_up(unsigned v, int delta) { int me = g_emu.cur; const uint64_t* a = emu_collect(v); return me >= delta ? (unsigned)a[me - delta] : v; }
-ZSA_DEV unsigned wv_shfl_xor(unsigned v, int mask) { int me = g_emu.cur; const uint64_t* a = emu_collect(v); return (unsigned)a[(me ^ mask) & 63]; }
-ZSA_DEV void wv_sync() { (void)emu_collect(0); }
+ZSA_DEV unsigned wv_shfl(unsigned v, int srcLane, int line = __builtin_LINE()) { const uint64_t* a = emu_collect(v, line); return (unsigned)a[srcLane & 63]; }
+ZSA_DEV unsigned wv_shfl_up(unsigned v, int delta, int line = __builtin_LINE()) { int me = g_emu.cur; const uint64_t* a = emu_collect(v, line); return me >= delta ? (unsigned)a[me - delta] : v; }
+ZSA_DEV unsigned wv_shfl_xor(unsigned v, int mask, int line = __builtin_LINE()) { int me = g_emu.cur; const uint64_t* a = emu_collect(v, line); return (unsigned)a[(me ^ mask) & 63]; }
+ZSA_DEV void wv_sync(int line = __builtin_LINE()) { (void)emu_collect(0, line); }
+ZSA_DEV void wv_lds_fence(int line = __builtin_LINE()) { (void)emu_collect(0, line); }
+ZSA_DEV unsigned wv_readlane(unsigned v, int srcLane, int line = __builtin_LINE()) { const uint64_t* a = emu_collect(v, line); return (unsigned)a[srcLane & 63]; }
+ZSA_DEV unsigned wv_alignbyte(unsigned hi, unsigned lo, unsigned sh) { return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (8 * (sh & 3))); }
 ZSA_DEV unsigned long long wv_clock() { return 0; }
 ZSA_DEV unsigned wv_atomic_add_lds(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 ZSA_DEV unsigned wv_atomic_or_lds(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
 ZSA_DEV unsigned wv_atomic_max_lds(unsigned* p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
 ZSA_DEV unsigned wv_atomic_add_global(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+ZSA_DEV void wv_atomic_max_global(unsigned* p, unsigned v) { if (v > *p) *p = v; }
+ZSA_DEV void wv_device_fence() {}
 
-ZSA_DEV unsigned wv_scan_incl(unsigned v)
+ZSA_DEV unsigned wv_scan_incl(unsigned v, int line = __builtin_LINE())
 {
-    int me = g_emu.cur; const uint64_t* a = emu_collect(v);
+    int me = g_emu.cur; const uint64_t* a = emu_collect(v, line);
     unsigned s = 0; for (int i = 0; i <= me; i++) s += (unsigned)a[i];
     return s;
 }
-ZSA_DEV unsigned wv_reduce_add(unsigned v) { const uint64_t* a = emu_collect(v); unsigned s = 0; for (int i = 0; i < 64; i++) s += (unsigned)a[i]; return s; }
-ZSA_DEV unsigned wv_reduce_max(unsigned v) { const uint64_t* a = emu_collect(v); unsigned s = 0; for (int i = 0; i < 64; i++) if ((unsigned)a[i] > s) s = (unsigned)a[i]; return s; }
+ZSA_DEV unsigned wv_reduce_add(unsigned v, int line = __builtin_LINE()) { const uint64_t* a = emu_collect(v, line); unsigned s = 0; for (int i = 0; i < 64; i++) s += (unsigned)a[i]; return s; }
+ZSA_DEV unsigned wv_reduce_max(unsigned v, int line = __builtin_LINE()) { const uint64_t* a = emu_collect(v, line); unsigned s = 0; for (int i = 0; i < 64; i++) if ((unsigned)a[i] > s) s = (unsigned)a[i]; return s; }
 
 // run `fn(arg)` on 64 lanes
 typedef void (*emu_kernel_fn)(void* arg);

@@ -43,19 +43,28 @@ struct ZsaCDictDev {            // digested compression dictionary, device resid
 struct ZsaHufNode { u32 count; u16 parent; u8 byte; u8 nbBits; };
 
 struct ZsaEncShared {
-    u32 count[256];
     ZsaHufCT hufPrev, hufNext;
     ZsaFseCT ll, of, ml;
-    ZsaHufNode node[2 * 256 + 2];
-    u16 rpBase[192], rpCurr[192];
-    u8  huffWeight[256];
-    s16 norm[256];
-    u16 cumul[258];
-    u8  tableSymbol[512];
-    // small FSE table for Huffman weights (tableLog <= 6, symbols <= 12)
-    u16 wtNext[64]; s32 wtDfs[16]; u32 wtDnb[16];
-    // batch scratch for the literal gather
-    u32 bLit[64], bSrc[64];
+    union {
+        struct {   // entropy stage of a block
+            u32 count[256];
+            ZsaHufNode node[2 * 256 + 2];
+            u16 rpBase[192], rpCurr[192];
+            u8  huffWeight[256];
+            s16 norm[256];
+            u16 cumul[258];
+            u8  tableSymbol[512];
+            // small FSE table for Huffman weights (tableLog <= 6, symbols <= 12)
+            u16 wtNext[64]; s32 wtDfs[16]; u32 wtDnb[16];
+            // batch scratch for the literal gather
+            u32 bLit[64], bSrc[64];
+        };
+        struct {   // parse stage of a block (zsa_parse.h): source ring + sequence staging
+            u32 ring[2048];
+            u64 seqStage[64];
+            u8  tags[4096];
+        };
+    };
     // entropy state carried between blocks (zstd_compress_internal.h ZSTD_compressedBlockState_t)
     u32 prevRep[3], nextRep[3];
     u32 prevHufRepeat, nextHufRepeat;
@@ -228,6 +237,8 @@ ZSA_DEV u32 zsa_parse_fast(u32* hashTable, const ZsaEncParams& P, const u8* base
     *lastLL = (u32)(iend - anchor);
     return nbSeq;
 }
+
+#include "zsa_parse.h"
 
 // zstd_compress_internal.h:780-793 ZSTD_count_2segments
 ZSA_DEV u32 zsa_count_2segments(const u8* ip, const u8* match, const u8* iEnd, const u8* mEnd, const u8* iStart)
@@ -1342,7 +1353,7 @@ ZSA_DEV void zsa_gatherLiterals(ZsaEncShared* S, const u64* seq, u32 nbSeq, cons
 }
 
 // ------------------------------------------------------------------ the frame (zstd_compress.c:4392-4632, 5107-5144)
-// hashTable: LDS, (1 << P.hlog) entries.  scratch: seq (u64 x (blockSizeMax/4 + 8)), lit (128 KiB + 64), tmp (lit-sized x 1.5 + 128).
+// hashTable: global memory (per-workgroup scratch, L2-resident), (1 << P.hlog) entries.  scratch: seq (u64 x (blockSizeMax/4 + 8)), lit (128 KiB + 64), tmp (lit-sized x 1.5 + 128).
 // Returns bytes written or (u64)-error (uniform).
 struct ZsaEncScratch { u64* seq; u8* lit; u8* tmp; };
 
@@ -1426,8 +1437,9 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
                     const u8* const dbase = cd->content - 2;
                     // loop bound: ip + 3 < (end - 8) + 2  <=>  index + 9 < cdictEnd
                     for (u32 idx = from + 3 * (u32)lane; idx + 9 < cdictEnd; idx += 3 * ZSA_WAVE)
-                        wv_atomic_max_lds(&hashTable[zsa_hash(zsa_ld64(dbase + idx), P.hlog, P.mml)], idx);
+                        wv_atomic_max_global(&hashTable[zsa_hash(zsa_ld64(dbase + idx), P.hlog, P.mml)], idx);
                 }
+                wv_device_fence();
                 wv_sync();
             }
             if (cdictLen != 0) {
@@ -1467,16 +1479,34 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
         u32 cSize = 0;
         ZSA_PROF(S, lane, 0);
         if (blockSize >= 7) {   // zstd_compress.c:3156
-            if (lane == 0) {
+            bool const dictParse = (Wn.lowLimit < Wn.dictLimit) || (Wn.dms != nullptr);
+            if (dictParse && lane == 0) {   // dictionary variants: serial (small payloads; many frames in flight instead)
                 u32 rep[3] = { S->prevRep[0], S->prevRep[1], S->prevRep[2] };
                 u32 lastLL = 0;
                 u32 nbSeq = 0xFFFFFFFFu;   // zstd_compress_internal.h:971-978 ZSTD_matchState_dictMode
                 if (Wn.lowLimit < Wn.dictLimit) nbSeq = zsa_parse_fast_ext(hashTable, P, Wn, ip, blockSize, rep, W.seq, &lastLL);
-                else if (Wn.dms) nbSeq = zsa_parse_fast_dms(hashTable, P, Wn, ip, blockSize, rep, W.seq, &lastLL);
-                if (nbSeq == 0xFFFFFFFFu)
-                    nbSeq = zsa_parse_fast(hashTable, P, Wn.base, Wn.dictLimit, Wn.loadedDictEnd, ip, blockSize, rep, W.seq, &lastLL);
+                else nbSeq = zsa_parse_fast_dms(hashTable, P, Wn, ip, blockSize, rep, W.seq, &lastLL);
                 S->nextRep[0] = rep[0]; S->nextRep[1] = rep[1]; S->nextRep[2] = rep[2];
                 S->u[EU_nbSeq] = nbSeq; S->u[EU_lastLL] = lastLL;
+            }
+            wv_sync();
+            if (!dictParse || S->u[EU_nbSeq] == 0xFFFFFFFFu) {
+                wv_sync();
+                u32 rep[3] = { S->prevRep[0], S->prevRep[1], S->prevRep[2] };
+                u32 lastLL = 0, nbSeq;
+                if (Wn.loadedDictEnd != 0) {   // contiguous-dictionary corner (extDict too small): serial plain parser
+                    nbSeq = 0;
+                    if (lane == 0) nbSeq = zsa_parse_fast(hashTable, P, Wn.base, Wn.dictLimit, Wn.loadedDictEnd, ip, blockSize, rep, W.seq, &lastLL);
+                    nbSeq = wv_shfl(nbSeq, 0); lastLL = wv_shfl(lastLL, 0);
+                    rep[0] = wv_shfl(rep[0], 0); rep[1] = wv_shfl(rep[1], 0);
+                } else {
+                    nbSeq = zsa_parse_fast_wave(hashTable, S->ring, S->seqStage, S->tags, P, Wn.base, Wn.dictLimit, ip, blockSize, rep, W.seq, &lastLL, lane);
+                }
+                wv_sync();
+                if (lane == 0) {
+                    S->nextRep[0] = rep[0]; S->nextRep[1] = rep[1]; S->nextRep[2] = rep[2];
+                    S->u[EU_nbSeq] = nbSeq; S->u[EU_lastLL] = lastLL;
+                }
             }
             wv_sync();
             ZSA_PROF(S, lane, 1);

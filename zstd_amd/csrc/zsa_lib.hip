@@ -19,7 +19,9 @@
 #define ZSA_SEQ_CAP   (ZSA_BLOCKSIZE_MAX / 4 + 64)          // packed sequences per block (zstd_compress.c:1642-1645)
 #define ZSA_LIT_CAP   (ZSA_BLOCKSIZE_MAX + 128)
 #define ZSA_TMP_CAP   (ZSA_BLOCKSIZE_MAX * 3 / 2 + 512)
-#define ZSA_ENC_SCRATCH_BYTES ((size_t)ZSA_SEQ_CAP * 8 + ZSA_LIT_CAP + ZSA_TMP_CAP)
+#define ZSA_MAX_HLOG  15
+#define ZSA_HT_BYTES   ((size_t)4 << ZSA_MAX_HLOG)           // hash table of the frame in flight (L2-resident)
+#define ZSA_ENC_SCRATCH_BYTES ((size_t)ZSA_SEQ_CAP * 8 + ZSA_LIT_CAP + ZSA_TMP_CAP + ZSA_HT_BYTES)
 #define ZSA_DEC_SCRATCH_BYTES ((size_t)ZSA_LIT_CAP)
 
 struct ZsaLaunchDict { const ZsaCDictDev* cd; const ZsaDDictDev* dd; };
@@ -51,13 +53,13 @@ __global__ void __launch_bounds__(64, 2)
 zsa_k_compress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
                u32* __restrict__ counter, u8* __restrict__ scratch, int level, u32 maxHlog, const ZsaCDictDev* cd, u64* __restrict__ prof)
 {
-    extern __shared__ __align__(16) u32 zsa_hashTable[];
     __shared__ ZsaEncShared S;
     __shared__ u32 nextFrame;
     if (threadIdx.x == 0) { for (int i = 0; i < ZSA_NPROF; i++) S.prof[i] = 0; S.profLast = wv_clock(); }
     u8* const wg = scratch + (size_t)blockIdx.x * ZSA_ENC_SCRATCH_BYTES;
     ZsaEncScratch W;
     W.seq = (u64*)wg; W.lit = wg + (size_t)ZSA_SEQ_CAP * 8; W.tmp = W.lit + ZSA_LIT_CAP;
+    u32* const zsa_hashTable = (u32*)(W.tmp + ZSA_TMP_CAP);
     for (;;) {
         if (threadIdx.x == 0) nextFrame = atomicAdd(counter, 1u);
         __syncthreads();
@@ -295,9 +297,9 @@ extern "C" size_t zsa_compress_enqueue(zsa_batch* b, int level, const zsa_CDict*
             if (!bad && cp.strat == 1 && cp.hlog > maxHlog) maxHlog = cp.hlog;
         }
     }
-    if (maxHlog > 15) maxHlog = 15;
-    size_t const dynLds = (size_t)4 << maxHlog;
-    size_t const ldsPerWG = dynLds + sizeof(ZsaEncShared) + 64;
+    if (maxHlog > ZSA_MAX_HLOG) maxHlog = ZSA_MAX_HLOG;
+    size_t const dynLds = 0;
+    size_t const ldsPerWG = sizeof(ZsaEncShared) + 64;
     static std::once_flag once;
     std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)zsa_k_compress, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); });
     unsigned const grid = zsa_grid(b, ldsPerWG);

@@ -1,0 +1,303 @@
+// zsa_parse.h -- the ZSTD_fast parse (zstd_fast.c:143-403, no dictionary) executed by all 64 lanes of the wave.
+//
+// The reference walks positions in pairs (ip0, ip0+1), then (ip0+step, ip0+step+1), ... and per pair performs, in
+// this order: a repcode check at the NEXT pair's first position, a hash-table check at ip0, a hash-table check at
+// ip0+1; every visited position also replaces its hash-table cell ("read the cell, then write my position", in
+// visiting order).  That is one serial chain, but everything between two matches can be evaluated speculatively:
+//
+//   * a WINDOW is ZSA_NP consecutive pairs.  Lane 3i evaluates the repcode check of pair i, lanes 3i+1 and 3i+2 the
+//     two hash checks -- lane order == the reference's event order, so the first set bit of one ballot is the event
+//     the reference would have stopped at;
+//   * the hash table lives in global memory (L2-resident, 4 << hashLog bytes per resident workgroup): keeping it out of
+//     LDS is what lets 8 workgroups share a CU, and the table gathers of one wave overlap with the work of the others;
+//   * all hash lanes read their cell; whether two lanes of the window share a cell is detected with a one-byte tag
+//     array in LDS (write my lane id at tag[h], read it back).  If not (the common case) the cell values are exactly
+//     what the serial walk would have seen.  Otherwise (runs of equal bytes) the nearest earlier lane with the same
+//     cell is found with a uniform readlane loop;
+//   * once the winning event is known, the lanes up to it store their positions (per cell, the last one in window
+//     order: positions grow with lane order);
+//   * match extension compares 64 x 8 bytes per step forwards and 64 bytes per step backwards, one ballot each.
+//
+// Source bytes come from an LDS ring that trails the parse position (filled 1 KiB per step with 16-byte coalesced loads),
+// so the per-sequence dependency chain is LDS latency except for match candidates older than the ring, which come
+// from L2.  Sequences are staged in LDS and written out 64 at a time.
+// Included by zsa_encode.h (uses zsa_hash / zsa_packseq / ZsaEncParams from there).
+#pragma once
+
+#define ZSA_RING_BYTES 8192u
+#define ZSA_RING_WORDS (ZSA_RING_BYTES / 4u)
+#define ZSA_NP 21          // pairs per window: 63 lanes
+#define ZSA_NTAGS 4096u    // one-byte tags for shared-cell detection
+
+struct ZsaRing {
+    u32* w;                // LDS, ZSA_RING_WORDS words; byte at frame offset o lives at byte (o & (ZSA_RING_BYTES-1))
+    const u8* src;         // frame start
+    u32 lo, hi;            // ring holds frame offsets [lo, hi)
+    u32 limit;             // no byte at or beyond this frame offset is ever read (end of the block being parsed)
+};
+
+ZSA_DEV u32 zsa_rd32(const ZsaRing& R, u32 o)
+{
+    if (o >= R.lo && o + 4 <= R.hi) {
+        u32 const w = o >> 2;
+        u32 const d0 = R.w[w & (ZSA_RING_WORDS - 1)], d1 = R.w[(w + 1) & (ZSA_RING_WORDS - 1)];
+        return wv_alignbyte(d1, d0, o & 3);
+    }
+    return zsa_ld32(R.src + o);
+}
+ZSA_DEV u64 zsa_rd64(const ZsaRing& R, u32 o)
+{
+    if (o >= R.lo && o + 8 <= R.hi) {
+        u32 const w = o >> 2;
+        u32 const d0 = R.w[w & (ZSA_RING_WORDS - 1)], d1 = R.w[(w + 1) & (ZSA_RING_WORDS - 1)], d2 = R.w[(w + 2) & (ZSA_RING_WORDS - 1)];
+        return (u64)wv_alignbyte(d1, d0, o & 3) | ((u64)wv_alignbyte(d2, d1, o & 3) << 32);
+    }
+    return zsa_ld64(R.src + o);
+}
+ZSA_DEV u32 zsa_rd8(const ZsaRing& R, u32 o)
+{
+    if (o >= R.lo && o < R.hi) return ((const u8*)R.w)[o & (ZSA_RING_BYTES - 1)];
+    return R.src[o];
+}
+// make [.., min(want, limit)) resident; `want` is uniform
+ZSA_DEV void zsa_ring_fill(ZsaRing& R, u32 want, int lane)
+{
+    wv_lds_fence();   // every lane is done reading the slots that are about to be replaced
+    while (R.hi < want && R.hi < R.limit) {
+        u32 const o = R.hi + 16u * (u32)lane;
+        u32 v[4] = { 0, 0, 0, 0 };
+        if (o + 16 <= R.limit) { v[0] = zsa_ld32(R.src + o); v[1] = zsa_ld32(R.src + o + 4); v[2] = zsa_ld32(R.src + o + 8); v[3] = zsa_ld32(R.src + o + 12); }
+        else if (o < R.limit) { for (u32 k = 0; k < R.limit - o; k++) v[k >> 2] |= (u32)R.src[o + k] << (8 * (k & 3)); }
+        u32* const d = R.w + ((o & (ZSA_RING_BYTES - 1)) >> 2);
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        R.hi += 1024;
+    }
+    if (R.hi - R.lo > ZSA_RING_BYTES) R.lo = R.hi - ZSA_RING_BYTES;
+    wv_lds_fence();
+}
+
+// common-prefix length of [ip, iend) and [m, ...), m < ip (ZSTD_count, zstd_compress_internal.h:755-774), all lanes;
+// arguments are frame offsets and uniform
+ZSA_DEV u32 zsa_count_wave(const ZsaRing& R, u32 ip, u32 m, u32 iend, int lane)
+{
+    u32 total = 0;
+    for (;;) {
+        u32 const a = ip + total + 8u * (u32)lane, b = m + total + 8u * (u32)lane;
+        u32 eq;
+        if (a + 8 <= iend) {
+            u64 const diff = zsa_rd64(R, a) ^ zsa_rd64(R, b);
+            eq = diff ? ((u32)__builtin_ctzll(diff) >> 3) : 8;
+        } else {
+            u32 const n = a < iend ? iend - a : 0;
+            eq = 0;
+            while (eq < n && zsa_rd8(R, a + eq) == zsa_rd8(R, b + eq)) eq++;
+        }
+        u64 const stop = wv_ballot(eq < 8);
+        if (stop) {
+            int const f = __builtin_ctzll(stop);
+            return total + 8u * (u32)f + wv_readlane(eq, f);
+        }
+        total += 512;
+    }
+}
+
+// Parses one block.  T: hash table (LDS).  base: window base (index i <-> base + i, the frame starts at index 2).
+// Returns the number of sequences appended to seqOut; rep[] and *lastLL are updated.  All values are wave-uniform.
+ZSA_DEV u32 zsa_parse_fast_wave(u32* T, u32* ringWords, u64* seqStage, u8* tags, const ZsaEncParams& P, const u8* base, u32 dictLimit,
+                                const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL, int lane)
+{
+    u32 const hlog = P.hlog, mls = P.mml;
+    u32 const stepSize = (P.tlen > 1) ? (P.tlen + 1) : 2;      // zstd_fast.c:153, :429
+    u32 const istart = (u32)(src - base), iend = istart + srcSize, ilimit = iend - 8;   // indices
+    u32 const maxDistance = 1u << P.wlog;
+    // ZSTD_getLowestPrefixIndex (zstd_compress_internal.h:1307-1318), no loaded dictionary
+    u32 const prefixStartIndex = (iend - dictLimit > maxDistance) ? iend - maxDistance : dictLimit;
+    ZsaRing R;
+    R.w = ringWords; R.src = base + 2; R.limit = iend - 2; R.lo = R.hi = (istart - 2) & ~1023u;
+#define RD32(i) zsa_rd32(R, (i) - 2)
+#define RD64(i) zsa_rd64(R, (i) - 2)
+#define RD8(i)  zsa_rd8(R, (i) - 2)
+    u32 anchor = istart, ip0 = istart;
+    u32 rep1 = rep[0], rep2 = rep[1], saved1 = 0, saved2 = 0, nbSeq = 0;
+    ip0 += (ip0 == prefixStartIndex);
+    {   u32 const curr = ip0;
+        u32 const windowLow = (curr - dictLimit > maxDistance) ? curr - maxDistance : dictLimit;
+        u32 const maxRep = curr - windowLow;
+        if (rep2 > maxRep) { saved2 = rep2; rep2 = 0; }
+        if (rep1 > maxRep) { saved1 = rep1; rep1 = 0; }
+    }
+    u32 const pair = (u32)lane / 3u, role = (u32)lane - 3u * pair;   // role 0: repcode check, 1: hash ip0, 2: hash ip0+1
+    bool const inWin = lane < 3 * ZSA_NP;
+    bool const hashLane = inWin && role != 0;
+
+    for (;;) {   // one search episode per iteration (label _start)
+        u32 step = stepSize, nextStep = ip0 + 128, sNext = stepSize;
+        if (ip0 + step + 1 >= ilimit) break;
+        bool blockDone = false;
+        for (;;) {   // one window per iteration
+            {   u32 const want = ip0 - 2 + 2048;
+                if (R.hi < want && R.hi < R.limit) zsa_ring_fill(R, want, lane);
+            }
+            // ---- positions of this window: P_0 = ip0, P_{i+1} = P_i + s_i, s_{i+1} = step at that time (zstd_fast.c:316-327)
+            u32 myP = ip0, myS = sNext, myC = step, endP, endS, endC, endNext;
+            if (ip0 + sNext + ZSA_NP * step < nextStep) {   // the step does not grow inside this window
+                if (pair != 0) { myP = ip0 + sNext + (pair - 1) * step; myS = step; }
+                endP = ip0 + sNext + (ZSA_NP - 1) * step; endS = step; endC = step; endNext = nextStep;
+            } else {
+                u32 Pi = ip0, si = sNext, ci = step, ns = nextStep;
+                for (u32 i = 0; i < ZSA_NP; i++) {
+                    if (i == pair) { myP = Pi; myS = si; myC = ci; }
+                    u32 const Pn = Pi + si, sn = ci;
+                    if (Pn + ci >= ns) { ci++; ns += 128; }
+                    Pi = Pn; si = sn;
+                }
+                endP = Pi; endS = si; endC = ci; endNext = ns;
+            }
+            bool const valid = inWin && (myP + myS + 1 < ilimit);      // the pair is entered: `ip3 < ilimit` (:328)
+            // ---- speculative evaluation
+            u32 const q = myP + (role == 2);
+            u32 const Pn = myP + myS;
+            u64 v = 0; u32 h = 0, old = 0, repA = 0, repB = 1;
+            if (valid && hashLane) { v = RD64(q); h = zsa_hash(v, hlog, mls); old = T[h]; }
+            if (valid && role == 0 && rep1 > 0) { repA = RD32(Pn); repB = RD32(Pn - rep1); }
+            if (valid && hashLane) tags[h & (ZSA_NTAGS - 1)] = (u8)lane;
+            wv_lds_fence();
+            u32 const back = (valid && hashLane) ? tags[h & (ZSA_NTAGS - 1)] : (u32)lane;
+            u64 const vm = wv_ballot(valid && hashLane);
+            bool const shared = wv_ballot(back != (u32)lane) != 0;
+            u32 cand = old;
+            if (shared) {   // nearest earlier position of this window in the same cell
+                for (int s = 1; s < 3 * ZSA_NP - 1; s++) {
+                    if (!((vm >> s) & 1)) continue;
+                    u32 const hs = wv_readlane(h, s), qs = wv_readlane(q, s);
+                    if (s < lane && hs == h) cand = qs;
+                }
+            }
+            bool ok = false;
+            if (valid && hashLane && cand >= prefixStartIndex) ok = (RD32(cand) == (u32)v);
+            if (role == 0) ok = valid && rep1 > 0 && repA == repB;
+            u64 const found = wv_ballot(ok);
+            u32 const nv = (u32)__builtin_popcountll(wv_ballot(valid && role == 1));
+
+            if (!found) {
+                // all positions of the window enter the table; per cell the last one in window order
+                bool dead = false;
+                if (shared) {
+                    for (int s = 2; s < 3 * ZSA_NP; s++) {
+                        if (!((vm >> s) & 1)) continue;
+                        u32 const hs = wv_readlane(h, s);
+                        if (s > lane && hs == h) dead = true;
+                    }
+                }
+                if (valid && hashLane && !dead) T[h] = q;
+                wv_lds_fence();
+                if (nv < ZSA_NP || !(endP + endS + 1 < ilimit)) { blockDone = true; break; }
+                ip0 = endP; sNext = endS; step = endC; nextStep = endNext;
+                continue;
+            }
+            // ---- the event the reference stops at
+            int const w = __builtin_ctzll(found);
+            u32 const wPair = (u32)w / 3u, wRole = (u32)w - 3u * wPair;
+            u32 const wP = wv_readlane(myP, w), wS = wv_readlane(myS, w), wC = wv_readlane(myC, w);
+            u32 const wCand = wv_readlane(cand, w);
+            // table: positions up to and including pair wPair stay (:266, :278, :300-303), plus P_{wPair+1} when the second
+            // check hit and step <= 4
+            bool const extra = (wRole == 2) && (wC <= 4);
+            u32 const xP = wP + wS;                                     // P_{wPair+1}
+            bool const xInWin = (wPair + 1 < ZSA_NP) && (wPair + 1 < nv);
+            bool const keep = valid && hashLane && (pair <= wPair || (extra && xInWin && pair == wPair + 1 && role == 1));
+            {   bool dead = false;
+                if (shared) {
+                    u64 const km = wv_ballot(keep);
+                    for (int s = 2; s < 3 * ZSA_NP; s++) {
+                        if (!((km >> s) & 1)) continue;
+                        u32 const hs = wv_readlane(h, s);
+                        if (s > lane && hs == h) dead = true;
+                    }
+                }
+                if (keep && !dead) T[h] = q;
+            }
+            wv_lds_fence();
+            if (extra && !xInWin) { u32 const hx = zsa_hash(RD64(xP), hlog, mls); if (lane == 0) T[hx] = xP; wv_lds_fence(); }
+
+            u32 current0, match0, mLength, offcode;
+            if (wRole == 0) {
+                current0 = wP;
+                ip0 = xP;
+                match0 = ip0 - rep1;
+                u32 const b1 = RD8(ip0 - 1) == RD8(match0 - 1);
+                ip0 -= b1; match0 -= b1;
+                offcode = 1;
+                mLength = 4 + b1;
+            } else {
+                current0 = wP + (wRole == 2);
+                ip0 = current0;
+                match0 = wCand;
+                rep2 = rep1;
+                rep1 = ip0 - match0;
+                offcode = rep1 + 3;
+                mLength = 4;
+                u32 const maxBack = (ip0 - anchor) < (match0 - prefixStartIndex) ? (ip0 - anchor) : (match0 - prefixStartIndex);
+                u32 nb = 0;
+                while (nb < maxBack) {   // :285-289, 64 bytes per step
+                    u32 const k = nb + (u32)lane;
+                    bool const e = (k < maxBack) && (RD8(ip0 - 1 - k) == RD8(match0 - 1 - k));
+                    u64 const ne = wv_ballot(!e);
+                    u32 const f = ne ? (u32)__builtin_ctzll(ne) : 64u;
+                    nb += f;
+                    if (f < 64) break;
+                }
+                ip0 -= nb; match0 -= nb; mLength += nb;
+            }
+            mLength += zsa_count_wave(R, ip0 + mLength - 2, match0 + mLength - 2, iend - 2, lane);
+            if (lane == 0) seqStage[nbSeq & 63] = zsa_packseq(ip0 - anchor, mLength - ZSA_MINMATCH, offcode);
+            nbSeq++;
+            if ((nbSeq & 63) == 0) { wv_lds_fence(); seqOut[nbSeq - 64 + (u32)lane] = seqStage[lane]; wv_lds_fence(); }
+            ip0 += mLength;
+            anchor = ip0;
+            if (ip0 <= ilimit) {
+                {   // :307-309, in this order
+                    u32 const pA = current0 + 2, pB = ip0 - 2;
+                    u32 hh = 0;
+                    if (lane < 2) hh = zsa_hash(RD64(lane == 0 ? pA : pB), hlog, mls);
+                    if (lane == 0) T[hh] = pA;
+                    wv_lds_fence();
+                    if (lane == 1) T[hh] = pB;
+                    wv_lds_fence();
+                }
+                if (rep2 > 0) {   // :311-324 immediate repcode
+                    while (ip0 <= ilimit && RD32(ip0) == RD32(ip0 - rep2)) {
+                        u32 const rLength = zsa_count_wave(R, ip0 + 4 - 2, ip0 + 4 - rep2 - 2, iend - 2, lane) + 4;
+                        { u32 const t = rep2; rep2 = rep1; rep1 = t; }
+                        {   u32 const hh = zsa_hash(RD64(ip0), hlog, mls);
+                            if (lane == 0) T[hh] = ip0;
+                            wv_lds_fence();
+                        }
+                        ip0 += rLength;
+                        if (lane == 0) seqStage[nbSeq & 63] = zsa_packseq(0, rLength - ZSA_MINMATCH, 1);
+                        nbSeq++;
+                        if ((nbSeq & 63) == 0) { wv_lds_fence(); seqOut[nbSeq - 64 + (u32)lane] = seqStage[lane]; wv_lds_fence(); }
+                        anchor = ip0;
+                        if (R.hi < ip0 - 2 + 1024 && R.hi < R.limit) zsa_ring_fill(R, ip0 - 2 + 2048, lane);
+                    }
+                }
+            }
+            break;   // goto _start
+        }
+        if (blockDone) break;
+    }
+#undef RD32
+#undef RD64
+#undef RD8
+    {   u32 const n = nbSeq & 63;
+        wv_lds_fence();
+        if ((u32)lane < n) seqOut[nbSeq - n + (u32)lane] = seqStage[lane];
+        wv_lds_fence();
+    }
+    // label _cleanup: zstd_fast.c:330-355
+    saved2 = ((saved1 != 0) && (rep1 != 0)) ? saved1 : saved2;
+    rep[0] = rep1 ? rep1 : saved1;
+    rep[1] = rep2 ? rep2 : saved2;
+    *lastLL = iend - anchor;
+    return nbSeq;
+}

@@ -17,11 +17,22 @@ ZSA_DEV unsigned wv_shfl_up(unsigned v, int delta) { return (unsigned)__shfl_up(
 ZSA_DEV unsigned wv_shfl_xor(unsigned v, int mask) { return (unsigned)__shfl_xor((int)v, mask, 64); }
 // Workgroup == one wave here: orders LDS and global accesses between the lanes of the wave.
 ZSA_DEV void wv_sync() { __syncthreads(); }
+// One wave per workgroup: LDS operations of a wave are issued and completed in order, so making one lane's LDS write
+// visible to another lane's later LDS read needs no s_barrier and no wait on outstanding global loads -- only a
+// compiler-level ordering point.
+ZSA_DEV void wv_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+// value of `v` in lane `srcLane`; srcLane must be wave-uniform
+ZSA_DEV unsigned wv_readlane(unsigned v, int srcLane) { return (unsigned)__builtin_amdgcn_readlane((int)v, srcLane); }
+// bytes [sh, sh+4) of the little-endian 8-byte value hi:lo, sh in 0..3
+ZSA_DEV unsigned wv_alignbyte(unsigned hi, unsigned lo, unsigned sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
 ZSA_DEV unsigned long long wv_clock() { return (unsigned long long)clock64(); }
 ZSA_DEV unsigned wv_atomic_add_lds(unsigned* p, unsigned v) { return atomicAdd(p, v); }
 ZSA_DEV unsigned wv_atomic_or_lds(unsigned* p, unsigned v) { return atomicOr(p, v); }
 ZSA_DEV unsigned wv_atomic_max_lds(unsigned* p, unsigned v) { return atomicMax(p, v); }
 ZSA_DEV unsigned wv_atomic_add_global(unsigned* p, unsigned v) { return atomicAdd(p, v); }
+ZSA_DEV void wv_atomic_max_global(unsigned* p, unsigned v) { (void)atomicMax(p, v); }
+// device-scope fence: afterwards plain loads of this wave observe earlier device-scope atomics (they bypass the L1)
+ZSA_DEV void wv_device_fence() { __threadfence(); }
 
 // inclusive prefix sum over the 64 lanes
 ZSA_DEV unsigned wv_scan_incl(unsigned v)
