@@ -70,6 +70,9 @@ ZSA_DEV void wv_sync(int line = __builtin_LINE()) { (void)emu_collect(0, line); 
 ZSA_DEV void wv_lds_fence(int line = __builtin_LINE()) { (void)emu_collect(0, line); }
 ZSA_DEV unsigned wv_readlane(unsigned v, int srcLane, int line = __builtin_LINE()) { const uint64_t* a = emu_collect(v, line); return (unsigned)a[srcLane & 63]; }
 ZSA_DEV unsigned wv_alignbyte(unsigned hi, unsigned lo, unsigned sh) { return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (8 * (sh & 3))); }
+ZSA_DEV unsigned wv_ldg8(const unsigned char* p) { return *p; }
+ZSA_DEV unsigned wv_ldg32(const unsigned char* p) { unsigned v; memcpy(&v, p, 4); return v; }
+ZSA_DEV unsigned long long wv_ldg64(const unsigned char* p) { unsigned long long v; memcpy(&v, p, 8); return v; }
 ZSA_DEV unsigned long long wv_clock() { return 0; }
 ZSA_DEV unsigned wv_atomic_add_lds(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 ZSA_DEV unsigned wv_atomic_or_lds(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }

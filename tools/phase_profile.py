@@ -14,7 +14,7 @@ enc, dec = zstd_amd.DeviceBatch(N), zstd_amd.DeviceBatch(N)
 enc.set_frames_strided(N, src.data_ptr(), FS, None, cbuf.data_ptr(), stride, bound)
 dec.set_frames_strided(N, cbuf.data_ptr(), stride, None, out.data_ptr(), FS, FS)
 enc.compress(1); dec.link_src_sizes(enc); dec.decompress(); torch.cuda.synchronize()
-ENC = ["init/hdr", "parse", "gather lits", "lit stats+huf build", "huf encode", "seq hist+tables", "seq encode", "finalize", "", "", "", "fetch work"]
+ENC = ["init/hdr", "parse (rest: post-match, rep2, ring)", "gather lits", "lit stats+huf build", "huf encode", "seq hist+tables", "seq encode", "finalize", "parse: window eval", "parse: winner+table", "parse: extension+store", "fetch work"]
 DEC = ["blk hdr/other", "huf table", "huf streams", "seq tables", "seq decode", "exec literals", "exec matches", "last lits", "", "", "", "fetch work"]
 for name, b, fn, labels in (("compress", enc, lambda: enc.compress(1), ENC), ("decompress", dec, lambda: dec.decompress(), DEC)):
     b.profile(True)

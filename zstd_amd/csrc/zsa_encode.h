@@ -60,7 +60,7 @@ struct ZsaEncShared {
             u32 bLit[64], bSrc[64];
         };
         struct {   // parse stage of a block (zsa_parse.h): source ring + sequence staging
-            u32 ring[2048];
+            u32 ring[2048 + 4];
             u64 seqStage[64];
             u8  tags[4096];
         };
@@ -1500,7 +1500,7 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
                     nbSeq = wv_shfl(nbSeq, 0); lastLL = wv_shfl(lastLL, 0);
                     rep[0] = wv_shfl(rep[0], 0); rep[1] = wv_shfl(rep[1], 0);
                 } else {
-                    nbSeq = zsa_parse_fast_wave(hashTable, S->ring, S->seqStage, S->tags, P, Wn.base, Wn.dictLimit, ip, blockSize, rep, W.seq, &lastLL, lane);
+                    nbSeq = zsa_parse_fast_wave(S, hashTable, S->ring, S->seqStage, S->tags, P, Wn.base, Wn.dictLimit, ip, blockSize, rep, W.seq, &lastLL, lane);
                 }
                 wv_sync();
                 if (lane == 0) {

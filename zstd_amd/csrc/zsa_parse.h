@@ -25,40 +25,35 @@
 #pragma once
 
 #define ZSA_RING_BYTES 8192u
-#define ZSA_RING_WORDS (ZSA_RING_BYTES / 4u)
-#define ZSA_NP 21          // pairs per window: 63 lanes
+#define ZSA_RING_WORDS (ZSA_RING_BYTES / 4u + 4u)   // + 16 bytes that mirror the first 16, so unaligned reads may run over the end
+#define ZSA_NP 10          // pairs per window: 30 lanes (matches come every ~3 positions on text-like data)
 #define ZSA_NTAGS 4096u    // one-byte tags for shared-cell detection
 
+#ifdef ZSA_PARSE_PROF
+#define ZSA_PPROF(S, lane, slot) ZSA_PROF(S, lane, slot)
+#else
+#define ZSA_PPROF(S, lane, slot) do {} while (0)
+#endif
+struct ZsaEncShared;
+
 struct ZsaRing {
-    u32* w;                // LDS, ZSA_RING_WORDS words; byte at frame offset o lives at byte (o & (ZSA_RING_BYTES-1))
+    u8* b;                 // LDS, ZSA_RING_BYTES + 16 bytes; byte at frame offset o lives at b[o & (ZSA_RING_BYTES-1)]
     const u8* src;         // frame start
     u32 lo, hi;            // ring holds frame offsets [lo, hi)
     u32 limit;             // no byte at or beyond this frame offset is ever read (end of the block being parsed)
 };
+struct __attribute__((packed)) ZsaPk64 { u64 v; };
+struct __attribute__((packed)) ZsaPk32 { u32 v; };
 
-ZSA_DEV u32 zsa_rd32(const ZsaRing& R, u32 o)
-{
-    if (o >= R.lo && o + 4 <= R.hi) {
-        u32 const w = o >> 2;
-        u32 const d0 = R.w[w & (ZSA_RING_WORDS - 1)], d1 = R.w[(w + 1) & (ZSA_RING_WORDS - 1)];
-        return wv_alignbyte(d1, d0, o & 3);
-    }
-    return zsa_ld32(R.src + o);
-}
-ZSA_DEV u64 zsa_rd64(const ZsaRing& R, u32 o)
-{
-    if (o >= R.lo && o + 8 <= R.hi) {
-        u32 const w = o >> 2;
-        u32 const d0 = R.w[w & (ZSA_RING_WORDS - 1)], d1 = R.w[(w + 1) & (ZSA_RING_WORDS - 1)], d2 = R.w[(w + 2) & (ZSA_RING_WORDS - 1)];
-        return (u64)wv_alignbyte(d1, d0, o & 3) | ((u64)wv_alignbyte(d2, d1, o & 3) << 32);
-    }
-    return zsa_ld64(R.src + o);
-}
-ZSA_DEV u32 zsa_rd8(const ZsaRing& R, u32 o)
-{
-    if (o >= R.lo && o < R.hi) return ((const u8*)R.w)[o & (ZSA_RING_BYTES - 1)];
-    return R.src[o];
-}
+// ring-only reads (gfx950 LDS handles unaligned ds_read_b32/b64): the caller guarantees residency
+ZSA_DEV u64 zsa_ring64(const ZsaRing& R, u32 o) { return ((const ZsaPk64*)(R.b + (o & (ZSA_RING_BYTES - 1))))->v; }
+ZSA_DEV u32 zsa_ring32(const ZsaRing& R, u32 o) { return ((const ZsaPk32*)(R.b + (o & (ZSA_RING_BYTES - 1))))->v; }
+ZSA_DEV u32 zsa_ring8(const ZsaRing& R, u32 o) { return R.b[o & (ZSA_RING_BYTES - 1)]; }
+// reads that fall back to global memory (L2) for bytes the ring no longer holds
+ZSA_DEV u32 zsa_rd32(const ZsaRing& R, u32 o) { return (o >= R.lo && o + 4 <= R.hi) ? zsa_ring32(R, o) : wv_ldg32(R.src + o); }
+ZSA_DEV u64 zsa_rd64(const ZsaRing& R, u32 o) { return (o >= R.lo && o + 8 <= R.hi) ? zsa_ring64(R, o) : wv_ldg64(R.src + o); }
+ZSA_DEV u32 zsa_rd8(const ZsaRing& R, u32 o) { return (o >= R.lo && o < R.hi) ? zsa_ring8(R, o) : wv_ldg8(R.src + o); }
+
 // make [.., min(want, limit)) resident; `want` is uniform
 ZSA_DEV void zsa_ring_fill(ZsaRing& R, u32 want, int lane)
 {
@@ -66,10 +61,12 @@ ZSA_DEV void zsa_ring_fill(ZsaRing& R, u32 want, int lane)
     while (R.hi < want && R.hi < R.limit) {
         u32 const o = R.hi + 16u * (u32)lane;
         u32 v[4] = { 0, 0, 0, 0 };
-        if (o + 16 <= R.limit) { v[0] = zsa_ld32(R.src + o); v[1] = zsa_ld32(R.src + o + 4); v[2] = zsa_ld32(R.src + o + 8); v[3] = zsa_ld32(R.src + o + 12); }
-        else if (o < R.limit) { for (u32 k = 0; k < R.limit - o; k++) v[k >> 2] |= (u32)R.src[o + k] << (8 * (k & 3)); }
-        u32* const d = R.w + ((o & (ZSA_RING_BYTES - 1)) >> 2);
+        if (o + 16 <= R.limit) { v[0] = wv_ldg32(R.src + o); v[1] = wv_ldg32(R.src + o + 4); v[2] = wv_ldg32(R.src + o + 8); v[3] = wv_ldg32(R.src + o + 12); }
+        else if (o < R.limit) { for (u32 k = 0; k < R.limit - o; k++) v[k >> 2] |= wv_ldg8(R.src + o + k) << (8 * (k & 3)); }
+        u32 const ro = o & (ZSA_RING_BYTES - 1);
+        u32* const d = (u32*)(R.b + ro);
         d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        if (ro == 0) { u32* const m = (u32*)(R.b + ZSA_RING_BYTES); m[0] = v[0]; m[1] = v[1]; m[2] = v[2]; m[3] = v[3]; }
         R.hi += 1024;
     }
     if (R.hi - R.lo > ZSA_RING_BYTES) R.lo = R.hi - ZSA_RING_BYTES;
@@ -101,19 +98,30 @@ ZSA_DEV u32 zsa_count_wave(const ZsaRing& R, u32 ip, u32 m, u32 iend, int lane)
     }
 }
 
-// Parses one block.  T: hash table (LDS).  base: window base (index i <-> base + i, the frame starts at index 2).
-// Returns the number of sequences appended to seqOut; rep[] and *lastLL are updated.  All values are wave-uniform.
-ZSA_DEV u32 zsa_parse_fast_wave(u32* T, u32* ringWords, u64* seqStage, u8* tags, const ZsaEncParams& P, const u8* base, u32 dictLimit,
-                                const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL, int lane)
+// ZSTD_hashPtr for a compile-time minMatch (zstd_compress_internal.h:809-846)
+template <int MLS> ZSA_DEV u32 zsa_hashT(u64 v, u32 hlog)
 {
-    u32 const hlog = P.hlog, mls = P.mml;
+    if (MLS <= 4) return ((u32)v * 2654435761U) >> (32 - hlog);
+    if (MLS == 5) return (u32)(((v << 24) * 889523592379ULL) >> (64 - hlog));
+    if (MLS == 6) return (u32)(((v << 16) * 227718039650203ULL) >> (64 - hlog));
+    if (MLS == 7) return (u32)(((v << 8) * 58295818150454627ULL) >> (64 - hlog));
+    return (u32)((v * 0xCF1BBCDCB7A56463ULL) >> (64 - hlog));
+}
+
+// Parses one block.  T: hash table (global, L2-resident).  base: window base (index i <-> base + i, the frame starts at
+// index 2).  Returns the number of sequences appended to seqOut; rep[] and *lastLL are updated.  All values are wave-uniform.
+template <int MLS>
+ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* seqStage, u8* tags, const ZsaEncParams& P, const u8* base, u32 dictLimit,
+                                 const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL, int lane)
+{
+    u32 const hlog = P.hlog;
     u32 const stepSize = (P.tlen > 1) ? (P.tlen + 1) : 2;      // zstd_fast.c:153, :429
     u32 const istart = (u32)(src - base), iend = istart + srcSize, ilimit = iend - 8;   // indices
     u32 const maxDistance = 1u << P.wlog;
     // ZSTD_getLowestPrefixIndex (zstd_compress_internal.h:1307-1318), no loaded dictionary
     u32 const prefixStartIndex = (iend - dictLimit > maxDistance) ? iend - maxDistance : dictLimit;
     ZsaRing R;
-    R.w = ringWords; R.src = base + 2; R.limit = iend - 2; R.lo = R.hi = (istart - 2) & ~1023u;
+    R.b = (u8*)ringWords; R.src = base + 2; R.limit = iend - 2; R.lo = R.hi = (istart - 2) & ~1023u;
 #define RD32(i) zsa_rd32(R, (i) - 2)
 #define RD64(i) zsa_rd64(R, (i) - 2)
 #define RD8(i)  zsa_rd8(R, (i) - 2)
@@ -129,6 +137,8 @@ ZSA_DEV u32 zsa_parse_fast_wave(u32* T, u32* ringWords, u64* seqStage, u8* tags,
     u32 const pair = (u32)lane / 3u, role = (u32)lane - 3u * pair;   // role 0: repcode check, 1: hash ip0, 2: hash ip0+1
     bool const inWin = lane < 3 * ZSA_NP;
     bool const hashLane = inWin && role != 0;
+    // with step 2 (level 1 until 128 bytes pass without a match) the lane's position is ip0 + a constant
+    u32 const fastOff = role == 0 ? 2u * pair + 2u : 2u * pair + (role == 2);
 
     for (;;) {   // one search episode per iteration (label _start)
         u32 step = stepSize, nextStep = ip0 + 128, sNext = stepSize;
@@ -138,13 +148,18 @@ ZSA_DEV u32 zsa_parse_fast_wave(u32* T, u32* ringWords, u64* seqStage, u8* tags,
             {   u32 const want = ip0 - 2 + 2048;
                 if (R.hi < want && R.hi < R.limit) zsa_ring_fill(R, want, lane);
             }
-            // ---- positions of this window: P_0 = ip0, P_{i+1} = P_i + s_i, s_{i+1} = step at that time (zstd_fast.c:316-327)
-            u32 myP = ip0, myS = sNext, myC = step, endP, endS, endC, endNext;
-            if (ip0 + sNext + ZSA_NP * step < nextStep) {   // the step does not grow inside this window
-                if (pair != 0) { myP = ip0 + sNext + (pair - 1) * step; myS = step; }
-                endP = ip0 + sNext + (ZSA_NP - 1) * step; endS = step; endC = step; endNext = nextStep;
+            // ---- positions of this window: P_0 = ip0, P_{i+1} = P_i + s_i, s_{i+1} = step at that time (zstd_fast.c:316-327).
+            // pos = the position this lane looks at: P_pair (+1) for the hash lanes, P_{pair+1} for the repcode lane.
+            bool const fast = (step == 2) & (sNext == 2) & (ip0 + 2 + ZSA_NP * 2 < nextStep);
+            u32 pos, myP = 0, myS = 2, myC = 2, endP, endS, endC, endNext;
+            bool valid;
+            if (fast) {
+                pos = ip0 + fastOff;
+                valid = inWin && (ip0 + 2 * pair + 3 < ilimit);            // the pair is entered: `ip3 < ilimit` (:328)
+                endP = ip0 + 2 * ZSA_NP; endS = 2; endC = 2; endNext = nextStep;
             } else {
                 u32 Pi = ip0, si = sNext, ci = step, ns = nextStep;
+#pragma unroll 1
                 for (u32 i = 0; i < ZSA_NP; i++) {
                     if (i == pair) { myP = Pi; myS = si; myC = ci; }
                     u32 const Pn = Pi + si, sn = ci;
@@ -152,44 +167,44 @@ ZSA_DEV u32 zsa_parse_fast_wave(u32* T, u32* ringWords, u64* seqStage, u8* tags,
                     Pi = Pn; si = sn;
                 }
                 endP = Pi; endS = si; endC = ci; endNext = ns;
+                pos = role == 0 ? myP + myS : myP + (role == 2);
+                valid = inWin && (myP + myS + 1 < ilimit);
             }
-            bool const valid = inWin && (myP + myS + 1 < ilimit);      // the pair is entered: `ip3 < ilimit` (:328)
-            // ---- speculative evaluation
-            u32 const q = myP + (role == 2);
-            u32 const Pn = myP + myS;
-            u64 v = 0; u32 h = 0, old = 0, repA = 0, repB = 1;
-            if (valid && hashLane) { v = RD64(q); h = zsa_hash(v, hlog, mls); old = T[h]; }
-            if (valid && role == 0 && rep1 > 0) { repA = RD32(Pn); repB = RD32(Pn - rep1); }
-            if (valid && hashLane) tags[h & (ZSA_NTAGS - 1)] = (u8)lane;
+            // ---- speculative evaluation: every lane compares 4 bytes at `pos` with 4 bytes at `cmpIdx`
+            u64 v = 0;
+            if (valid) v = fast ? zsa_ring64(R, pos - 2) : RD64(pos);
+            u32 h = 0, old = 0;
+            if (valid && hashLane) { h = zsa_hashT<MLS>(v, hlog); old = T[h]; tags[h & (ZSA_NTAGS - 1)] = (u8)lane; }
             wv_lds_fence();
             u32 const back = (valid && hashLane) ? tags[h & (ZSA_NTAGS - 1)] : (u32)lane;
-            u64 const vm = wv_ballot(valid && hashLane);
             bool const shared = wv_ballot(back != (u32)lane) != 0;
-            u32 cand = old;
+            u64 const vm = wv_ballot(valid && hashLane);
+            u32 cmpIdx = role == 0 ? pos - rep1 : old;
             if (shared) {   // nearest earlier position of this window in the same cell
-                for (int s = 1; s < 3 * ZSA_NP - 1; s++) {
-                    if (!((vm >> s) & 1)) continue;
-                    u32 const hs = wv_readlane(h, s), qs = wv_readlane(q, s);
-                    if (s < lane && hs == h) cand = qs;
+                for (u64 m = vm; m; m &= m - 1) {   // ascending: the last hit is the nearest earlier lane
+                    int const s = __builtin_ctzll(m);
+                    u32 const hs = wv_readlane(h, s), qs = wv_readlane(pos, s);
+                    if (hashLane && s < lane && hs == h) cmpIdx = qs;
                 }
             }
+            bool const eligible = valid && (role == 0 ? rep1 > 0 : cmpIdx >= prefixStartIndex);
             bool ok = false;
-            if (valid && hashLane && cand >= prefixStartIndex) ok = (RD32(cand) == (u32)v);
-            if (role == 0) ok = valid && rep1 > 0 && repA == repB;
+            if (eligible) ok = RD32(cmpIdx) == (u32)v;
             u64 const found = wv_ballot(ok);
-            u32 const nv = (u32)__builtin_popcountll(wv_ballot(valid && role == 1));
+            ZSA_PPROF(S, lane, 8);
+            u32 const nv = (u32)__builtin_popcountll(vm) >> 1;
 
             if (!found) {
                 // all positions of the window enter the table; per cell the last one in window order
                 bool dead = false;
                 if (shared) {
-                    for (int s = 2; s < 3 * ZSA_NP; s++) {
-                        if (!((vm >> s) & 1)) continue;
+                    for (u64 m = vm; m; m &= m - 1) {
+                        int const s = __builtin_ctzll(m);
                         u32 const hs = wv_readlane(h, s);
                         if (s > lane && hs == h) dead = true;
                     }
                 }
-                if (valid && hashLane && !dead) T[h] = q;
+                if (valid && hashLane && !dead) T[h] = pos;
                 wv_lds_fence();
                 if (nv < ZSA_NP || !(endP + endS + 1 < ilimit)) { blockDone = true; break; }
                 ip0 = endP; sNext = endS; step = endC; nextStep = endNext;
@@ -198,8 +213,10 @@ ZSA_DEV u32 zsa_parse_fast_wave(u32* T, u32* ringWords, u64* seqStage, u8* tags,
             // ---- the event the reference stops at
             int const w = __builtin_ctzll(found);
             u32 const wPair = (u32)w / 3u, wRole = (u32)w - 3u * wPair;
-            u32 const wP = wv_readlane(myP, w), wS = wv_readlane(myS, w), wC = wv_readlane(myC, w);
-            u32 const wCand = wv_readlane(cand, w);
+            u32 wP, wS, wC;
+            if (fast) { wP = ip0 + 2 * wPair; wS = 2; wC = 2; }
+            else { wP = wv_readlane(myP, w); wS = wv_readlane(myS, w); wC = wv_readlane(myC, w); }
+            u32 const wCand = wv_readlane(cmpIdx, w);
             // table: positions up to and including pair wPair stay (:266, :278, :300-303), plus P_{wPair+1} when the second
             // check hit and step <= 4
             bool const extra = (wRole == 2) && (wC <= 4);
@@ -209,17 +226,18 @@ ZSA_DEV u32 zsa_parse_fast_wave(u32* T, u32* ringWords, u64* seqStage, u8* tags,
             {   bool dead = false;
                 if (shared) {
                     u64 const km = wv_ballot(keep);
-                    for (int s = 2; s < 3 * ZSA_NP; s++) {
-                        if (!((km >> s) & 1)) continue;
+                    for (u64 m = km; m; m &= m - 1) {
+                        int const s = __builtin_ctzll(m);
                         u32 const hs = wv_readlane(h, s);
                         if (s > lane && hs == h) dead = true;
                     }
                 }
-                if (keep && !dead) T[h] = q;
+                if (keep && !dead) T[h] = pos;
             }
             wv_lds_fence();
-            if (extra && !xInWin) { u32 const hx = zsa_hash(RD64(xP), hlog, mls); if (lane == 0) T[hx] = xP; wv_lds_fence(); }
+            if (extra && !xInWin) { u32 const hx = zsa_hashT<MLS>(RD64(xP), hlog); if (lane == 0) T[hx] = xP; wv_lds_fence(); }
 
+            ZSA_PPROF(S, lane, 9);
             u32 current0, match0, mLength, offcode;
             if (wRole == 0) {
                 current0 = wP;
@@ -255,21 +273,23 @@ ZSA_DEV u32 zsa_parse_fast_wave(u32* T, u32* ringWords, u64* seqStage, u8* tags,
             if ((nbSeq & 63) == 0) { wv_lds_fence(); seqOut[nbSeq - 64 + (u32)lane] = seqStage[lane]; wv_lds_fence(); }
             ip0 += mLength;
             anchor = ip0;
+            ZSA_PPROF(S, lane, 10);
             if (ip0 <= ilimit) {
+                if (R.hi < ip0 - 2 + 1024 && R.hi < R.limit) zsa_ring_fill(R, ip0 - 2 + 2048, lane);
                 {   // :307-309, in this order
                     u32 const pA = current0 + 2, pB = ip0 - 2;
                     u32 hh = 0;
-                    if (lane < 2) hh = zsa_hash(RD64(lane == 0 ? pA : pB), hlog, mls);
+                    if (lane < 2) hh = zsa_hashT<MLS>(RD64(lane == 0 ? pA : pB), hlog);
                     if (lane == 0) T[hh] = pA;
                     wv_lds_fence();
                     if (lane == 1) T[hh] = pB;
                     wv_lds_fence();
                 }
                 if (rep2 > 0) {   // :311-324 immediate repcode
-                    while (ip0 <= ilimit && RD32(ip0) == RD32(ip0 - rep2)) {
+                    while (ip0 <= ilimit && zsa_ring32(R, ip0 - 2) == RD32(ip0 - rep2)) {
                         u32 const rLength = zsa_count_wave(R, ip0 + 4 - 2, ip0 + 4 - rep2 - 2, iend - 2, lane) + 4;
                         { u32 const t = rep2; rep2 = rep1; rep1 = t; }
-                        {   u32 const hh = zsa_hash(RD64(ip0), hlog, mls);
+                        {   u32 const hh = zsa_hashT<MLS>(zsa_ring64(R, ip0 - 2), hlog);
                             if (lane == 0) T[hh] = ip0;
                             wv_lds_fence();
                         }
@@ -300,4 +320,15 @@ ZSA_DEV u32 zsa_parse_fast_wave(u32* T, u32* ringWords, u64* seqStage, u8* tags,
     rep[1] = rep2 ? rep2 : saved2;
     *lastLL = iend - anchor;
     return nbSeq;
+}
+
+ZSA_DEV u32 zsa_parse_fast_wave(ZsaEncShared* S, u32* T, u32* ringWords, u64* seqStage, u8* tags, const ZsaEncParams& P, const u8* base, u32 dictLimit,
+                                const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL, int lane)
+{
+    switch (P.mml) {
+    case 5:  return zsa_parse_fast_waveT<5>(S, T, ringWords, seqStage, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, lane);
+    case 6:  return zsa_parse_fast_waveT<6>(S, T, ringWords, seqStage, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, lane);
+    case 7:  return zsa_parse_fast_waveT<7>(S, T, ringWords, seqStage, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, lane);
+    default: return zsa_parse_fast_waveT<4>(S, T, ringWords, seqStage, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, lane);
+    }
 }

@@ -25,6 +25,13 @@ ZSA_DEV void wv_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefron
 ZSA_DEV unsigned wv_readlane(unsigned v, int srcLane) { return (unsigned)__builtin_amdgcn_readlane((int)v, srcLane); }
 // bytes [sh, sh+4) of the little-endian 8-byte value hi:lo, sh in 0..3
 ZSA_DEV unsigned wv_alignbyte(unsigned hi, unsigned lo, unsigned sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
+// loads from a pointer known to be global memory (frame descriptors hand out generic pointers: without this the compiler
+// emits flat_load, which also ties up the LDS counter); unaligned addresses are fine on gfx950
+struct __attribute__((packed)) WvPk32 { unsigned v; };
+struct __attribute__((packed)) WvPk64 { unsigned long long v; };
+ZSA_DEV unsigned wv_ldg8(const unsigned char* p) { return *(const __attribute__((address_space(1))) unsigned char*)p; }
+ZSA_DEV unsigned wv_ldg32(const unsigned char* p) { return ((const __attribute__((address_space(1))) WvPk32*)p)->v; }
+ZSA_DEV unsigned long long wv_ldg64(const unsigned char* p) { return ((const __attribute__((address_space(1))) WvPk64*)p)->v; }
 ZSA_DEV unsigned long long wv_clock() { return (unsigned long long)clock64(); }
 ZSA_DEV unsigned wv_atomic_add_lds(unsigned* p, unsigned v) { return atomicAdd(p, v); }
 ZSA_DEV unsigned wv_atomic_or_lds(unsigned* p, unsigned v) { return atomicOr(p, v); }
