@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzstd_amd.so")
+LIB_PATH = os.environ.get("ZSTD_AMD_LIB") or os.path.join(_HERE, "libzstd_amd.so")   # override: A/B builds of the same ABI
 
 c_size_p = ctypes.POINTER(ctypes.c_size_t)
 c_void_pp = ctypes.POINTER(ctypes.c_void_p)

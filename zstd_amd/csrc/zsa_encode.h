@@ -41,6 +41,8 @@ struct ZsaCDictDev {            // digested compression dictionary, device resid
 };
 
 struct ZsaHufNode { u32 count; u16 parent; u8 byte; u8 nbBits; };
+// scratch of the sequence encoder; overlays ZsaEncShared::node (Huffman tree nodes are dead by then)
+struct ZsaSeqEncScratch { u8 code[3][64]; u16 stBits[3][64]; u8 stNb[3][64]; u32 bitbuf[256]; };
 
 struct ZsaEncShared {
     ZsaHufCT hufPrev, hufNext;
@@ -1281,37 +1283,101 @@ ZSA_DEV u32 zsa_entropyCompress(ZsaEncShared* S, const u64* seq, u32 nbSeq, cons
             wv_sync();
         }
         ZSA_PROF(S, lane, 5);
-        // zstd_compress_sequences.c:291-383 ZSTD_encodeSequences_body, lane 0
-        if (lane == 0) {
-            *seqHead = (u8)((types[0] << 6) + (types[1] << 4) + (types[2] << 2));
-            ZsaBitW w;
-            ZsaFseCState sML, sOF, sLL;
-            zsa_bw_init(w, op);
-            {   u64 const s = seq[nbSeq - 1];
-                u32 const ll = zsa_seq_ll(s), ml = zsa_seq_ml(s), of = zsa_seq_of(s);
-                u32 const llc = zsa_LLcode(ll), mlc = zsa_MLcode(ml), ofc = zsa_highbit32(of);
-                zsa_fse_initCState2(sML, S->ml.nextState, S->ml.dfs, S->ml.dnb, S->ml.tableLog, mlc);
-                zsa_fse_initCState2(sOF, S->of.nextState, S->of.dfs, S->of.dnb, S->of.tableLog, ofc);
-                zsa_fse_initCState2(sLL, S->ll.nextState, S->ll.dfs, S->ll.dnb, S->ll.tableLog, llc);
-                zsa_bw_add(w, ll, zsa_LL_bits(llc));
-                zsa_bw_add(w, ml, zsa_ML_bits(mlc));
-                zsa_bw_add(w, of, ofc);
+        // zstd_compress_sequences.c:291-383 ZSTD_encodeSequences_body.  The bitstream is written last sequence first; the
+        // only serial parts are the three FSE state chains, which are independent of each other.  64 sequences at a
+        // time: all lanes derive codes and extra bits, lanes 0/1/2 walk the OF/ML/LL state chains over the 64 codes,
+        // all lanes assemble their sequence's bits, a prefix sum places them, LDS atomic-or packs them, and whole
+        // words are flushed to the output together.
+        if (lane == 0) *seqHead = (u8)((types[0] << 6) + (types[1] << 4) + (types[2] << 2));
+        {
+            ZsaSeqEncScratch* const E = (ZsaSeqEncScratch*)S->node;
+            for (u32 i = (u32)lane; i < 256; i += ZSA_WAVE) E->bitbuf[i] = 0;
+            const ZsaFseCT* const myCT = lane == 0 ? &S->of : (lane == 1 ? &S->ml : &S->ll);
+            ZsaFseCState st; st.value = 0; st.next = myCT->nextState; st.dfs = myCT->dfs; st.dnb = myCT->dnb; st.stateLog = myCT->tableLog;
+            u32 totalBits = 0, flushedWords = 0;
+            wv_lds_fence();
+            for (u32 tBase = 0; tBase < nbSeq; tBase += ZSA_WAVE) {
+                u32 const cnt = (nbSeq - tBase) < ZSA_WAVE ? (nbSeq - tBase) : ZSA_WAVE;
+                bool const mine = (u32)lane < cnt;
+                u32 ll = 0, ml = 0, of = 1, llc = 0, mlc = 0, ofc = 0;
+                if (mine) {
+                    u64 const sq = seq[nbSeq - 1 - (tBase + (u32)lane)];
+                    ll = zsa_seq_ll(sq); ml = zsa_seq_ml(sq); of = zsa_seq_of(sq);
+                    llc = zsa_LLcode(ll); mlc = zsa_MLcode(ml); ofc = zsa_highbit32(of);
+                    E->code[0][lane] = (u8)ofc; E->code[1][lane] = (u8)mlc; E->code[2][lane] = (u8)llc;
+                }
+                wv_lds_fence();
+                if (lane < 3) {   // the three state chains, side by side
+                    for (u32 j = 0; j < cnt; j++) {
+                        u32 const sym = E->code[lane][j];
+                        if (tBase + j == 0) {   // FSE_initCState2 with the last sequence's code
+                            zsa_fse_initCState2(st, st.next, st.dfs, st.dnb, st.stateLog, sym);
+                            E->stBits[lane][j] = 0; E->stNb[lane][j] = 0;
+                        } else {
+                            u32 const nbBitsOut = (st.value + st.dnb[sym]) >> 16;
+                            E->stBits[lane][j] = (u16)(st.value & ((1u << nbBitsOut) - 1u));
+                            E->stNb[lane][j] = (u8)nbBitsOut;
+                            st.value = st.next[(s32)(st.value >> nbBitsOut) + st.dfs[sym]];
+                        }
+                    }
+                }
+                wv_lds_fence();
+                // this sequence's bits, in emission order: OF/ML/LL state bits, then LL/ML/OF extra bits
+                u64 lo = 0, hi = 0; u32 len = 0;
+#define ZSA_BLOB_ADD(val, nb) do { u32 const nb_ = (nb); u64 const v_ = (u64)(val); if (nb_) { if (len < 64) { lo |= v_ << len; if (len + nb_ > 64) hi |= v_ >> (64 - len); } else hi |= v_ << (len - 64); len += nb_; } } while (0)
+                if (mine) {
+                    ZSA_BLOB_ADD(E->stBits[0][lane], E->stNb[0][lane]);
+                    ZSA_BLOB_ADD(E->stBits[1][lane], E->stNb[1][lane]);
+                    ZSA_BLOB_ADD(E->stBits[2][lane], E->stNb[2][lane]);
+                    { u32 const b = zsa_LL_bits(llc); ZSA_BLOB_ADD(ll & ((1u << b) - 1u), b); }
+                    { u32 const b = zsa_ML_bits(mlc); ZSA_BLOB_ADD(ml & ((1u << b) - 1u), b); }
+                    ZSA_BLOB_ADD(of & ((1u << ofc) - 1u), ofc);
+                }
+                u32 const incl = wv_scan_incl(len);
+                u32 const chunkBits = wv_readlane(incl, 63);
+                if (mine && len) {
+                    u32 const rel = totalBits + (incl - len) - flushedWords * 32;
+                    u32 const w = rel >> 5, sh = rel & 31;
+                    u64 const nlo = lo << sh, nhi = (hi << sh) | (sh ? (lo >> (64 - sh)) : 0);
+                    if ((u32)nlo) wv_atomic_or_lds(&E->bitbuf[w], (u32)nlo);
+                    if ((u32)(nlo >> 32)) wv_atomic_or_lds(&E->bitbuf[w + 1], (u32)(nlo >> 32));
+                    if ((u32)nhi) wv_atomic_or_lds(&E->bitbuf[w + 2], (u32)nhi);
+                    if ((u32)(nhi >> 32)) wv_atomic_or_lds(&E->bitbuf[w + 3], (u32)(nhi >> 32));
+                }
+                totalBits += chunkBits;
+                wv_lds_fence();
+                {   // flush whole words, carry the partial one
+                    u32 const done = (totalBits >> 5) - flushedWords;
+                    for (u32 i = (u32)lane; i < done; i += ZSA_WAVE) { u32 const wv_ = E->bitbuf[i]; __builtin_memcpy(op + 4 * (flushedWords + i), &wv_, 4); }
+                    u32 const carry = E->bitbuf[done];
+                    wv_lds_fence();
+                    for (u32 i = (u32)lane; i <= done + 4 && i < 256; i += ZSA_WAVE) E->bitbuf[i] = 0;
+                    wv_lds_fence();
+                    if (lane == 0) E->bitbuf[0] = carry;
+                    flushedWords += done;
+                    wv_lds_fence();
+                }
             }
-            for (u32 n = nbSeq - 2; n < nbSeq; n--) {
-                u64 const s = seq[n];
-                u32 const ll = zsa_seq_ll(s), ml = zsa_seq_ml(s), of = zsa_seq_of(s);
-                u32 const llc = zsa_LLcode(ll), mlc = zsa_MLcode(ml), ofc = zsa_highbit32(of);
-                zsa_fse_encodeSymbol(w, sOF, ofc);
-                zsa_fse_encodeSymbol(w, sML, mlc);
-                zsa_fse_encodeSymbol(w, sLL, llc);
-                zsa_bw_add(w, ll, zsa_LL_bits(llc));
-                zsa_bw_add(w, ml, zsa_ML_bits(mlc));
-                zsa_bw_add(w, of, ofc);
+            // FSE_flushCState x3 (ML, OF, LL) + end mark (bitstream.h:229-241)
+            u32 const vOF = wv_readlane(st.value, 0), vML = wv_readlane(st.value, 1), vLL = wv_readlane(st.value, 2);
+            {   u64 lo = 0, hi = 0; u32 len = 0;
+                ZSA_BLOB_ADD(vML & ((1u << S->ml.tableLog) - 1u), S->ml.tableLog);
+                ZSA_BLOB_ADD(vOF & ((1u << S->of.tableLog) - 1u), S->of.tableLog);
+                ZSA_BLOB_ADD(vLL & ((1u << S->ll.tableLog) - 1u), S->ll.tableLog);
+                ZSA_BLOB_ADD(1u, 1);
+                if (lane == 0) {
+                    u32 const rel = totalBits - flushedWords * 32;
+                    u32 const w = rel >> 5, sh = rel & 31;
+                    u64 const nlo = lo << sh, nhi = sh ? (lo >> (64 - sh)) : 0;
+                    E->bitbuf[w] |= (u32)nlo; E->bitbuf[w + 1] |= (u32)(nlo >> 32); E->bitbuf[w + 2] |= (u32)nhi;
+                }
+                totalBits += len;
             }
-            zsa_bw_add(w, sML.value, sML.stateLog);
-            zsa_bw_add(w, sOF.value, sOF.stateLog);
-            zsa_bw_add(w, sLL.value, sLL.stateLog);
-            S->u[EU_tmp] = zsa_bw_close(w);
+#undef ZSA_BLOB_ADD
+            wv_lds_fence();
+            u32 const totalBytes = (totalBits + 7) >> 3;
+            for (u32 i = flushedWords * 4 + (u32)lane; i < totalBytes; i += ZSA_WAVE) op[i] = ((const u8*)E->bitbuf)[i - flushedWords * 4];
+            if (lane == 0) S->u[EU_tmp] = totalBytes;
         }
         wv_sync();
         u32 const bitstreamSize = S->u[EU_tmp];

@@ -16,6 +16,9 @@
 // ------------------------------------------------------------------------------------------------ kernels
 // One 64-lane workgroup per frame at a time; workgroups pull frame indices from a device counter, so a launch
 // of (CUs x resident workgroups) keeps every CU busy however frame costs vary.
+#ifndef ZSA_ENC_VGPRS
+#define ZSA_ENC_VGPRS 256
+#endif
 #define ZSA_SEQ_CAP   (ZSA_BLOCKSIZE_MAX / 4 + 64)          // packed sequences per block (zstd_compress.c:1642-1645)
 #define ZSA_LIT_CAP   (ZSA_BLOCKSIZE_MAX + 128)
 #define ZSA_TMP_CAP   (ZSA_BLOCKSIZE_MAX * 3 / 2 + 512)
@@ -49,7 +52,7 @@ zsa_k_decompress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ resu
     if (prof && threadIdx.x == 0) for (int i = 0; i < ZSA_NPROF; i++) atomicAdd((unsigned long long*)&prof[i], (unsigned long long)S.prof[i]);
 }
 
-__global__ void __launch_bounds__(64, 2)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(ZSA_ENC_VGPRS)))
 zsa_k_compress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
                u32* __restrict__ counter, u8* __restrict__ scratch, int level, u32 maxHlog, const ZsaCDictDev* cd, u64* __restrict__ prof)
 {

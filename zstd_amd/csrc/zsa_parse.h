@@ -26,8 +26,12 @@
 
 #define ZSA_RING_BYTES 8192u
 #define ZSA_RING_WORDS (ZSA_RING_BYTES / 4u + 4u)   // + 16 bytes that mirror the first 16, so unaligned reads may run over the end
+#ifndef ZSA_NP
 #define ZSA_NP 10          // pairs per window: 30 lanes (matches come every ~3 positions on text-like data)
+#endif
+#ifndef ZSA_NTAGS
 #define ZSA_NTAGS 4096u    // one-byte tags for shared-cell detection
+#endif
 
 #ifdef ZSA_PARSE_PROF
 #define ZSA_PPROF(S, lane, slot) ZSA_PROF(S, lane, slot)
@@ -98,6 +102,46 @@ ZSA_DEV u32 zsa_count_wave(const ZsaRing& R, u32 ip, u32 m, u32 iend, int lane)
     }
 }
 
+// One round of match extension: lanes 0..47 compare 8 bytes each forwards from (ip, m) (capped at iend), lanes 48..63
+// one byte each backwards from (ipB-1, mB-1) for at most maxBack bytes -- both directions ride on the same memory
+// round trip.  Returns forward length in *fwd and backward length in *bwd (both complete: longer runs loop).
+ZSA_DEV void zsa_extend_wave(const ZsaRing& R, u32 ip, u32 m, u32 iend, u32 ipB, u32 mB, u32 maxBack, u32* fwd, u32* bwd, int lane)
+{
+    bool stop;
+    u32 eq = 0;
+    if (lane < 48) {
+        u32 const a = ip + 8u * (u32)lane, b = m + 8u * (u32)lane;
+        if (a + 8 <= iend) {
+            u64 const diff = zsa_rd64(R, a) ^ zsa_rd64(R, b);
+            eq = diff ? ((u32)__builtin_ctzll(diff) >> 3) : 8;
+        } else {
+            u32 const n = a < iend ? iend - a : 0;
+            while (eq < n && zsa_rd8(R, a + eq) == zsa_rd8(R, b + eq)) eq++;
+        }
+        stop = eq < 8;
+    } else {
+        u32 const k = (u32)lane - 48u;
+        stop = !((k < maxBack) && (zsa_rd8(R, ipB - 1 - k) == zsa_rd8(R, mB - 1 - k)));
+    }
+    u64 const sb = wv_ballot(stop);
+    u64 const sf = sb & 0xFFFFFFFFFFFFull, sk = sb >> 48;
+    if (sf) { int const f = __builtin_ctzll(sf); *fwd = 8u * (u32)f + wv_readlane(eq, f); }
+    else *fwd = 384 + zsa_count_wave(R, ip + 384, m + 384, iend, lane);
+    if (sk) *bwd = (u32)__builtin_ctzll(sk);
+    else {
+        u32 nb = 16;
+        while (nb < maxBack) {   // zstd_fast.c:285-289, 64 bytes per step
+            u32 const k = nb + (u32)lane;
+            bool const e = (k < maxBack) && (zsa_rd8(R, ipB - 1 - k) == zsa_rd8(R, mB - 1 - k));
+            u64 const ne = wv_ballot(!e);
+            u32 const f = ne ? (u32)__builtin_ctzll(ne) : 64u;
+            nb += f;
+            if (f < 64) break;
+        }
+        *bwd = nb;
+    }
+}
+
 // ZSTD_hashPtr for a compile-time minMatch (zstd_compress_internal.h:809-846)
 template <int MLS> ZSA_DEV u32 zsa_hashT(u64 v, u32 hlog)
 {
@@ -140,9 +184,29 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
     // with step 2 (level 1 until 128 bytes pass without a match) the lane's position is ip0 + a constant
     u32 const fastOff = role == 0 ? 2u * pair + 2u : 2u * pair + (role == 2);
 
+    // The immediate-repcode check that follows every match (zstd_fast.c:311-324) rides along with the next window as one
+    // more event (lane 63) that precedes all others: its compare shares the window's memory round trip.
+    bool chkRep2 = false;
     for (;;) {   // one search episode per iteration (label _start)
         u32 step = stepSize, nextStep = ip0 + 128, sNext = stepSize;
-        if (ip0 + step + 1 >= ilimit) break;
+        if (ip0 + step + 1 >= ilimit) {
+            // no room for a window: finish the immediate-repcode loop on its own
+            while (chkRep2 && ip0 <= ilimit && zsa_ring32(R, ip0 - 2) == RD32(ip0 - rep2)) {
+                u32 const rLength = zsa_count_wave(R, ip0 + 4 - 2, ip0 + 4 - rep2 - 2, iend - 2, lane) + 4;
+                { u32 const t = rep2; rep2 = rep1; rep1 = t; }
+                {   u32 const hh = zsa_hashT<MLS>(zsa_ring64(R, ip0 - 2), hlog);
+                    if (lane == 0) T[hh] = ip0;
+                    wv_lds_fence();
+                }
+                ip0 += rLength;
+                if (lane == 0) seqStage[nbSeq & 63] = zsa_packseq(0, rLength - ZSA_MINMATCH, 1);
+                nbSeq++;
+                if ((nbSeq & 63) == 0) { wv_lds_fence(); seqOut[nbSeq - 64 + (u32)lane] = seqStage[lane]; wv_lds_fence(); }
+                anchor = ip0;
+                if (R.hi < ip0 - 2 + 1024 && R.hi < R.limit) zsa_ring_fill(R, ip0 - 2 + 2048, lane);
+            }
+            break;
+        }
         bool blockDone = false;
         for (;;) {   // one window per iteration
             {   u32 const want = ip0 - 2 + 2048;
@@ -171,15 +235,17 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
                 valid = inWin && (myP + myS + 1 < ilimit);
             }
             // ---- speculative evaluation: every lane compares 4 bytes at `pos` with 4 bytes at `cmpIdx`
+            bool const r2lane = chkRep2 && lane == 63;                      // ip0 <= ilimit holds: a window fits
+            if (r2lane) { pos = ip0; valid = true; }
             u64 v = 0;
-            if (valid) v = fast ? zsa_ring64(R, pos - 2) : RD64(pos);
+            if (valid) v = (fast || r2lane) ? zsa_ring64(R, pos - 2) : RD64(pos);
             u32 h = 0, old = 0;
             if (valid && hashLane) { h = zsa_hashT<MLS>(v, hlog); old = T[h]; tags[h & (ZSA_NTAGS - 1)] = (u8)lane; }
             wv_lds_fence();
             u32 const back = (valid && hashLane) ? tags[h & (ZSA_NTAGS - 1)] : (u32)lane;
             bool const shared = wv_ballot(back != (u32)lane) != 0;
             u64 const vm = wv_ballot(valid && hashLane);
-            u32 cmpIdx = role == 0 ? pos - rep1 : old;
+            u32 cmpIdx = r2lane ? pos - rep2 : (role == 0 ? pos - rep1 : old);
             if (shared) {   // nearest earlier position of this window in the same cell
                 for (u64 m = vm; m; m &= m - 1) {   // ascending: the last hit is the nearest earlier lane
                     int const s = __builtin_ctzll(m);
@@ -187,12 +253,29 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
                     if (hashLane && s < lane && hs == h) cmpIdx = qs;
                 }
             }
-            bool const eligible = valid && (role == 0 ? rep1 > 0 : cmpIdx >= prefixStartIndex);
+            bool const eligible = valid && (r2lane ? true : (role == 0 ? rep1 > 0 : cmpIdx >= prefixStartIndex));
             bool ok = false;
             if (eligible) ok = RD32(cmpIdx) == (u32)v;
             u64 const found = wv_ballot(ok);
             ZSA_PPROF(S, lane, 8);
             u32 const nv = (u32)__builtin_popcountll(vm) >> 1;
+            if (found >> 63) {   // immediate repcode: nothing of the speculative window happened
+                u32 const rLength = zsa_count_wave(R, ip0 + 4 - 2, ip0 + 4 - rep2 - 2, iend - 2, lane) + 4;
+                { u32 const t = rep2; rep2 = rep1; rep1 = t; }
+                {   u32 const hh = zsa_hashT<MLS>(wv_readlane((u32)v, 63) | ((u64)wv_readlane((u32)(v >> 32), 63) << 32), hlog);
+                    if (lane == 0) T[hh] = ip0;
+                    wv_lds_fence();
+                }
+                ip0 += rLength;
+                if (lane == 0) seqStage[nbSeq & 63] = zsa_packseq(0, rLength - ZSA_MINMATCH, 1);
+                nbSeq++;
+                if ((nbSeq & 63) == 0) { wv_lds_fence(); seqOut[nbSeq - 64 + (u32)lane] = seqStage[lane]; wv_lds_fence(); }
+                anchor = ip0;
+                chkRep2 = (ip0 <= ilimit) && rep2 > 0;
+                ZSA_PPROF(S, lane, 10);
+                break;   // back to _start with the new ip0
+            }
+            chkRep2 = false;
 
             if (!found) {
                 // all positions of the window enter the table; per cell the last one in window order
@@ -238,15 +321,13 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
             if (extra && !xInWin) { u32 const hx = zsa_hashT<MLS>(RD64(xP), hlog); if (lane == 0) T[hx] = xP; wv_lds_fence(); }
 
             ZSA_PPROF(S, lane, 9);
-            u32 current0, match0, mLength, offcode;
+            u32 current0, match0, mLength, offcode, maxBack;
             if (wRole == 0) {
                 current0 = wP;
                 ip0 = xP;
                 match0 = ip0 - rep1;
-                u32 const b1 = RD8(ip0 - 1) == RD8(match0 - 1);
-                ip0 -= b1; match0 -= b1;
                 offcode = 1;
-                mLength = 4 + b1;
+                maxBack = 1;                                           // :262 `ip0[-1] == match0[-1]`, unconditional
             } else {
                 current0 = wP + (wRole == 2);
                 ip0 = current0;
@@ -254,20 +335,13 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
                 rep2 = rep1;
                 rep1 = ip0 - match0;
                 offcode = rep1 + 3;
-                mLength = 4;
-                u32 const maxBack = (ip0 - anchor) < (match0 - prefixStartIndex) ? (ip0 - anchor) : (match0 - prefixStartIndex);
-                u32 nb = 0;
-                while (nb < maxBack) {   // :285-289, 64 bytes per step
-                    u32 const k = nb + (u32)lane;
-                    bool const e = (k < maxBack) && (RD8(ip0 - 1 - k) == RD8(match0 - 1 - k));
-                    u64 const ne = wv_ballot(!e);
-                    u32 const f = ne ? (u32)__builtin_ctzll(ne) : 64u;
-                    nb += f;
-                    if (f < 64) break;
-                }
-                ip0 -= nb; match0 -= nb; mLength += nb;
+                maxBack = (ip0 - anchor) < (match0 - prefixStartIndex) ? (ip0 - anchor) : (match0 - prefixStartIndex);
             }
-            mLength += zsa_count_wave(R, ip0 + mLength - 2, match0 + mLength - 2, iend - 2, lane);
+            {   u32 fwd, bwd;
+                zsa_extend_wave(R, ip0 + 4 - 2, match0 + 4 - 2, iend - 2, ip0 - 2, match0 - 2, maxBack, &fwd, &bwd, lane);
+                ip0 -= bwd; match0 -= bwd;
+                mLength = 4 + bwd + fwd;
+            }
             if (lane == 0) seqStage[nbSeq & 63] = zsa_packseq(ip0 - anchor, mLength - ZSA_MINMATCH, offcode);
             nbSeq++;
             if ((nbSeq & 63) == 0) { wv_lds_fence(); seqOut[nbSeq - 64 + (u32)lane] = seqStage[lane]; wv_lds_fence(); }
@@ -285,22 +359,7 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
                     if (lane == 1) T[hh] = pB;
                     wv_lds_fence();
                 }
-                if (rep2 > 0) {   // :311-324 immediate repcode
-                    while (ip0 <= ilimit && zsa_ring32(R, ip0 - 2) == RD32(ip0 - rep2)) {
-                        u32 const rLength = zsa_count_wave(R, ip0 + 4 - 2, ip0 + 4 - rep2 - 2, iend - 2, lane) + 4;
-                        { u32 const t = rep2; rep2 = rep1; rep1 = t; }
-                        {   u32 const hh = zsa_hashT<MLS>(zsa_ring64(R, ip0 - 2), hlog);
-                            if (lane == 0) T[hh] = ip0;
-                            wv_lds_fence();
-                        }
-                        ip0 += rLength;
-                        if (lane == 0) seqStage[nbSeq & 63] = zsa_packseq(0, rLength - ZSA_MINMATCH, 1);
-                        nbSeq++;
-                        if ((nbSeq & 63) == 0) { wv_lds_fence(); seqOut[nbSeq - 64 + (u32)lane] = seqStage[lane]; wv_lds_fence(); }
-                        anchor = ip0;
-                        if (R.hi < ip0 - 2 + 1024 && R.hi < R.limit) zsa_ring_fill(R, ip0 - 2 + 2048, lane);
-                    }
-                }
+                chkRep2 = rep2 > 0;   // :311-324 immediate repcode: evaluated with the next window
             }
             break;   // goto _start
         }
