@@ -965,6 +965,10 @@ ZSA_DEV u32 zsa_huf_encode1X(u8* dst, const u8* src, u32 srcSize, const ZsaHufCT
     return zsa_bw_close(w);
 }
 
+// The same stream written by all lanes: 256 symbols per step (4 per lane, last symbol first), prefix sum of the code
+// lengths, LDS atomic-or packing, whole words flushed together.  Returns the stream size (uniform).
+ZSA_DEV u32 zsa_huf_encode_wave(ZsaEncShared* S, u8* dst, const u8* src, u32 srcSize, const ZsaHufCT* ct, int lane);
+
 // all-lane histogram of bytes into S->count[0..255] (hist.c:30-165): exact counts
 ZSA_DEV void zsa_hist_bytes(ZsaEncShared* S, const u8* src, u32 n, int lane)
 {
@@ -972,6 +976,58 @@ ZSA_DEV void zsa_hist_bytes(ZsaEncShared* S, const u8* src, u32 n, int lane)
     wv_sync();
     for (u32 i = (u32)lane; i < n; i += ZSA_WAVE) wv_atomic_add_lds(&S->count[src[i]], 1);
     wv_sync();
+}
+
+ZSA_DEV u32 zsa_huf_encode_wave(ZsaEncShared* S, u8* dst, const u8* src, u32 srcSize, const ZsaHufCT* ct, int lane)
+{
+    ZsaSeqEncScratch* const E = (ZsaSeqEncScratch*)S->node;
+    for (u32 i = (u32)lane; i < 256; i += ZSA_WAVE) E->bitbuf[i] = 0;
+    u32 totalBits = 0, flushedWords = 0;
+    wv_lds_fence();
+    for (u32 tBase = 0; tBase < srcSize; tBase += 4 * ZSA_WAVE) {
+        u64 blob = 0; u32 len = 0;
+        u32 const t0 = tBase + 4u * (u32)lane;
+        for (u32 k = 0; k < 4; k++) {
+            u32 const t = t0 + k;
+            if (t < srcSize) {
+                u32 const sym = src[srcSize - 1 - t];
+                u32 const nb = ct->nbBits[sym];
+                blob |= (u64)ct->val[sym] << len;
+                len += nb;
+            }
+        }
+        u32 const incl = wv_scan_incl(len);
+        u32 const chunkBits = wv_readlane(incl, 63);
+        if (len) {
+            u32 const rel = totalBits + (incl - len) - flushedWords * 32;
+            u32 const w = rel >> 5, sh = rel & 31;
+            u64 const nlo = blob << sh;
+            u32 const nhi = sh ? (u32)(blob >> (64 - sh)) : 0;
+            if ((u32)nlo) wv_atomic_or_lds(&E->bitbuf[w], (u32)nlo);
+            if ((u32)(nlo >> 32)) wv_atomic_or_lds(&E->bitbuf[w + 1], (u32)(nlo >> 32));
+            if (nhi) wv_atomic_or_lds(&E->bitbuf[w + 2], nhi);
+        }
+        totalBits += chunkBits;
+        wv_lds_fence();
+        {   u32 const done = (totalBits >> 5) - flushedWords;
+            for (u32 i = (u32)lane; i < done; i += ZSA_WAVE) { u32 const wv_ = E->bitbuf[i]; __builtin_memcpy(dst + 4 * (flushedWords + i), &wv_, 4); }
+            u32 const carry = E->bitbuf[done];
+            wv_lds_fence();
+            for (u32 i = (u32)lane; i <= done + 4 && i < 256; i += ZSA_WAVE) E->bitbuf[i] = 0;
+            wv_lds_fence();
+            if (lane == 0) E->bitbuf[0] = carry;
+            flushedWords += done;
+            wv_lds_fence();
+        }
+    }
+    // HUF_closeCStream (huf_compress.c:941-950): end mark, flush
+    if (lane == 0) { u32 const rel = totalBits - flushedWords * 32; E->bitbuf[rel >> 5] |= 1u << (rel & 31); }
+    totalBits += 1;
+    wv_lds_fence();
+    u32 const totalBytes = (totalBits + 7) >> 3;
+    for (u32 i = flushedWords * 4 + (u32)lane; i < totalBytes; i += ZSA_WAVE) dst[i] = ((const u8*)E->bitbuf)[i - flushedWords * 4];
+    wv_lds_fence();
+    return totalBytes;
 }
 
 // ------------------------------------------------------------------ literals section (zstd_compress_literals.c:130-236)
@@ -1074,28 +1130,21 @@ ZSA_DEV u32 zsa_compressLiterals(ZsaEncShared* S, u8* dst, const u8* lit, u32 li
         u8* const op = ostart + hSize;
         u32 total = 0;
         if (singleStream) {
-            if (lane == 0) S->u[EU_s0] = zsa_huf_encode1X(op, lit, litSize, ct);
-            wv_sync();
-            total = S->u[EU_s0];
+            total = zsa_huf_encode_wave(S, op, lit, litSize, ct, lane);
         } else if (litSize >= 12) {
-            // huf_compress.c:1135-1183: 6-byte jump table, 4 segments of (n+3)/4; each lane packs one stream into tmp
+            // huf_compress.c:1135-1183: 6-byte jump table, 4 segments of (n+3)/4, written one after the other
             u32 const segmentSize = (litSize + 3) / 4;
-            u32 const segBound = segmentSize + (segmentSize >> 1) + 16;     // 11 bits/symbol worst case
-            if (lane < 4) {
-                u32 const beg = (u32)lane * segmentSize;
-                u32 const len = (lane == 3) ? litSize - 3 * segmentSize : segmentSize;
-                S->u[EU_s0 + lane] = zsa_huf_encode1X(tmp + (u32)lane * segBound, lit + beg, len, ct);
+            u32 c[4], at = 6;
+            for (u32 k = 0; k < 4; k++) {
+                u32 const beg = k * segmentSize;
+                u32 const len = (k == 3) ? litSize - 3 * segmentSize : segmentSize;
+                c[k] = zsa_huf_encode_wave(S, op + at, lit + beg, len, ct, lane);
+                at += c[k];
             }
-            wv_sync();
-            u32 const c0 = S->u[EU_s0], c1 = S->u[EU_s1], c2 = S->u[EU_s2], c3 = S->u[EU_s3];
-            if (c0 > 65535 || c1 > 65535 || c2 > 65535 || c3 > 65535) total = 0;
+            if (c[0] > 65535 || c[1] > 65535 || c[2] > 65535 || c[3] > 65535) total = 0;
             else {
-                if (lane == 0) { zsa_st16(op, c0); zsa_st16(op + 2, c1); zsa_st16(op + 4, c2); }
-                for (u32 i = (u32)lane; i < c0; i += ZSA_WAVE) op[6 + i] = tmp[i];
-                for (u32 i = (u32)lane; i < c1; i += ZSA_WAVE) op[6 + c0 + i] = tmp[segBound + i];
-                for (u32 i = (u32)lane; i < c2; i += ZSA_WAVE) op[6 + c0 + c1 + i] = tmp[2 * segBound + i];
-                for (u32 i = (u32)lane; i < c3; i += ZSA_WAVE) op[6 + c0 + c1 + c2 + i] = tmp[3 * segBound + i];
-                total = 6 + c0 + c1 + c2 + c3;
+                if (lane == 0) { zsa_st16(op, c[0]); zsa_st16(op + 2, c[1]); zsa_st16(op + 4, c[2]); }
+                total = at;
             }
         }
         // huf_compress.c:1192-1207 HUF_compressCTable_internal
