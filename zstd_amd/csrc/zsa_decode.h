@@ -31,6 +31,7 @@ struct ZsaDDictDev {            // digested dictionary, device resident (zstd_dd
     const ZsaSeqCell *ll, *of, *ml;
 };
 
+#define ZSA_BITSTAGE 768u    // >= 64 sequences x 89 bits + 8
 struct ZsaDecShared {
     ZsaSeqCell ll[512], ml[512], of[256];
     u16 huf[1 << ZSA_HUF_TABLELOG_MAX];
@@ -43,7 +44,9 @@ struct ZsaDecShared {
     u32 fseCell[64];            // weights FSE table: newState | symbol<<16 | nbBits<<24
     u32 rankVal[ZSA_HUF_TABLELOG_MAX + 2];
     // one batch of decoded sequences
-    u32 seqLL[64], seqML[64], seqOF[64], outStart[64], litStart[64];
+    u32 seqLL[64], seqML[64], seqOF[64], outStart[64], litStart[64], mStart[64];
+    // the part of the sequence bitstream the next batch reads (it is consumed downwards), staged by all lanes
+    u8  bits[ZSA_BITSTAGE + 16];
     // uniform state published by lane 0
     u64 result;                 // final return value of the frame walk
     u32 err;                    // first error raised inside the current block (0 = none)
@@ -105,6 +108,30 @@ ZSA_DEV int zsa_br_reload(ZsaBitR& b)
     b.ptr -= nbBytes;
     b.bitsConsumed -= nbBytes * 8;
     b.container = zsa_ld64(b.ptr);
+    return result;
+}
+// BIT_reloadDStream with the refill served from the LDS copy of [stageLo, stageHi) when it covers the 8 bytes
+ZSA_DEV u64 zsa_br_fetch(const u8* p, const u8* stage, const u8* stageLo, const u8* stageHi)
+{
+    if (p >= stageLo && p + 8 <= stageHi) { struct __attribute__((packed)) Pk { u64 v; }; return ((const Pk*)(stage + (p - stageLo)))->v; }
+    return zsa_ld64(p);
+}
+ZSA_DEV int zsa_br_reload_staged(ZsaBitR& b, const u8* stage, const u8* stageLo, const u8* stageHi)
+{
+    if (b.bitsConsumed > 64) return ZB_overflow;
+    if (b.ptr >= b.start + 8) {
+        b.ptr -= b.bitsConsumed >> 3;
+        b.bitsConsumed &= 7;
+        b.container = zsa_br_fetch(b.ptr, stage, stageLo, stageHi);
+        return ZB_unfinished;
+    }
+    if (b.ptr == b.start) return (b.bitsConsumed < 64) ? ZB_endOfBuffer : ZB_completed;
+    u32 nbBytes = b.bitsConsumed >> 3;
+    int result = ZB_unfinished;
+    if (b.ptr - nbBytes < b.start) { nbBytes = (u32)(b.ptr - b.start); result = ZB_endOfBuffer; }
+    b.ptr -= nbBytes;
+    b.bitsConsumed -= nbBytes * 8;
+    b.container = zsa_br_fetch(b.ptr, stage, stageLo, stageHi);
     return result;
 }
 ZSA_DEV bool zsa_br_end(const ZsaBitR& b) { return (b.ptr == b.start) && (b.bitsConsumed == 64); }
@@ -549,6 +576,20 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
         u32 fencedPos = outPos;
         while (nbSeq) {
             u32 const n = nbSeq < ZSA_WAVE ? nbSeq : ZSA_WAVE;
+            // -- stage the bytes this batch can consume (<= 64 x 89 bits below ptr + 8) into LDS, 16 per lane
+            const u8* stageHi; const u8* stageLo;
+            {   u64 const p64 = (u64)(size_t)b.ptr;
+                u32 const plo = wv_readlane((u32)p64, 0), phi = wv_readlane((u32)(p64 >> 32), 0);
+                const u8* const ptr0 = (const u8*)(size_t)(((u64)phi << 32) | plo);
+                const u8* const secEnd = src + S->u[ZU_tmp] + S->u[ZU_seqSize];
+                stageHi = (ptr0 + 8 <= secEnd) ? ptr0 + 8 : secEnd;
+                stageLo = ((size_t)(stageHi - (src + S->u[ZU_tmp])) > ZSA_BITSTAGE) ? stageHi - ZSA_BITSTAGE : src + S->u[ZU_tmp];
+                const u8* const c = stageLo + 16u * (u32)lane;
+                if (c + 16 <= stageHi) { u64 const a0 = zsa_ld64(c), a1 = zsa_ld64(c + 8); __builtin_memcpy(S->bits + 16u * (u32)lane, &a0, 8); __builtin_memcpy(S->bits + 16u * (u32)lane + 8, &a1, 8); }
+                else if (c < stageHi) { for (u32 k = 0; c + k < stageHi; k++) S->bits[16u * (u32)lane + k] = c[k]; }
+                wv_sync();
+            }
+#define ZSA_RELOAD(b) zsa_br_reload_staged(b, S->bits, stageLo, stageHi)
             // -- zstd_decompress_block.c:1185-1299 ZSTD_decodeSequence, n times on lane 0
             if (lane == 0) {
                 for (u32 i = 0; i < n; i++) {
@@ -575,17 +616,18 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                         }
                     }
                     if (mlBits > 0) matchLength += zsa_br_readFast(b, mlBits);
-                    if (totalBits >= 57 - (ZSA_LLFSELog + ZSA_MLFSELog + ZSA_OffFSELog)) zsa_br_reload(b);
+                    if (totalBits >= 57 - (ZSA_LLFSELog + ZSA_MLFSELog + ZSA_OffFSELog)) ZSA_RELOAD(b);
                     if (llBits > 0) litLength += zsa_br_readFast(b, llBits);
                     stLL = (u32)((ll >> 32) & 0xFFFF) + zsa_br_read(b, (u32)(ll >> 56));
                     stML = (u32)((ml >> 32) & 0xFFFF) + zsa_br_read(b, (u32)(ml >> 56));
                     stOF = (u32)((of >> 32) & 0xFFFF) + zsa_br_read(b, (u32)(of >> 56));
                     S->seqLL[i] = litLength; S->seqML[i] = matchLength; S->seqOF[i] = offset;
-                    if (i + 1 < n || nbSeq > n) zsa_br_reload(b);
+                    if (i + 1 < n || nbSeq > n) ZSA_RELOAD(b);
                 }
                 // last batch: exact-end check (zstd_decompress_block.c:1639), reported after the batch has executed
-                S->u[ZU_batchN] = (nbSeq == n) && (zsa_br_reload(b) < ZB_completed);
+                S->u[ZU_batchN] = (nbSeq == n) && (ZSA_RELOAD(b) < ZB_completed);
             }
+#undef ZSA_RELOAD
             ZSA_PROF(S, lane, 4);
             wv_sync();
             // -- execute the batch (zstd_decompress_block.c:873-1060 semantics)
@@ -620,8 +662,32 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
             wv_sync();
             if (fencedPos < outPos) fencedPos = outPos;   // everything before this batch is visible now
             ZSA_PROF(S, lane, 5);
-            // matches, in order
-            for (u32 i = 0; i < n; i++) {
+            // matches.  Phase I: every match whose source lies entirely before this batch's output (already visible) is
+            // independent of the batch -- all of them are copied at once, flattened over the lanes.
+            u32 const myO = outPos + myOutStart + myLL;
+            u32 const mySpan = myOF < myML ? myOF : myML;
+            bool const indep = (u32)lane < n && ((u64)myO + mySpan <= (u64)myOF + outPos);
+            u32 const mIncl = wv_scan_incl(indep ? myML : 0);
+            S->mStart[lane] = mIncl - (indep ? myML : 0);
+            u64 const depMask = wv_ballot((u32)lane < n && !indep && myML > 0);
+            u32 const totalInd = wv_shfl(mIncl, 63);
+            wv_sync();
+            for (u32 t = (u32)lane; t < totalInd; t += ZSA_WAVE) {
+                u32 lo = 0, hi = n - 1;
+                while (lo < hi) { u32 const mid = (lo + hi + 1) >> 1; if (S->mStart[mid] <= t) lo = mid; else hi = mid - 1; }
+                // lo = last sequence whose independent bytes start at or before t (sequences that contribute none share a start
+                // with their successor and are skipped by taking the last)
+                u32 const k = t - S->mStart[lo];
+                u32 const off = S->seqOF[lo], ml = S->seqML[lo];
+                u32 const o = outPos + S->outStart[lo] + S->seqLL[lo];
+                s64 const p = (s64)o - (s64)off + (off >= ml ? k : k % off);
+                dst[o + k] = p < 0 ? C.dictContent[(s64)C.dictSize + p] : dst[p];
+            }
+            if (depMask) wv_sync();   // phase II may read what phase I wrote
+            if (fencedPos < outPos) fencedPos = outPos;
+            // Phase II: the others, in order
+            for (u64 m = depMask; m; m &= m - 1) {
+                u32 const i = (u32)__builtin_ctzll(m);
                 u32 const ml = S->seqML[i], off = S->seqOF[i];
                 u32 const o = outPos + S->outStart[i] + S->seqLL[i];
                 u32 const span = off < ml ? off : ml;            // distinct source bytes
