@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/prof/<tag>_* (tools/collect_profiles.sh) into the committed summaries under profiles/:
+<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats), <tag>_pmc.json (per-kernel, per-launch counter averages,
+HBM traffic with the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md) and the bench line of the traced run."""
+import collections, csv, glob, json, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", "prof")
+dst = os.path.join(ROOT, "profiles")
+
+
+def find(d, suffix):
+    r = glob.glob(os.path.join(src, d, "**", "*" + suffix), recursive=True)
+    return r[0] if r else None
+
+
+ks = find(tag + "_trace", "kernel_stats.csv")
+if ks:
+    shutil.copy(ks, os.path.join(dst, tag + "_kernel_stats.csv"))
+for line in open(os.path.join(src, tag + "_trace.log"), errors="replace"):
+    if line.startswith('{"metric"'):
+        open(os.path.join(dst, tag + "_bench_under_trace.json"), "w").write(line)
+pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in ("_fetch", "_write", "_sq", "_sq2"):
+    f = find(tag + d, "counter_collection.csv")
+    if not f:
+        continue
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        if not k.startswith("zsa_k_"):
+            continue
+        per[(k, r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
+    for (k, _), cs in per.items():
+        for c, v in cs.items():
+            pmc[k][c].append(v)
+out = {}
+for k, cs in pmc.items():
+    out[k] = {c: sum(v) / len(v) for c, v in cs.items()}
+    out[k]["launches_averaged"] = max(len(v) for v in cs.values())
+    if "FETCH_SIZE" in out[k] and "WRITE_SIZE" in out[k]:
+        # rocprofv3 reports KiB; on gfx950 FETCH_SIZE tallies 128-B read requests at 64 B (guide, section HBM): x2
+        out[k]["hbm_read_bytes_corrected"] = out[k]["FETCH_SIZE"] * 1024 * 2
+        out[k]["hbm_write_bytes"] = out[k]["WRITE_SIZE"] * 1024
+        out[k]["hbm_traffic_bytes"] = out[k]["hbm_read_bytes_corrected"] + out[k]["hbm_write_bytes"]
+json.dump(out, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
+print(json.dumps(out, indent=1, sort_keys=True))

@@ -280,6 +280,7 @@ static unsigned zsa_grid(const zsa_batch* b, size_t ldsPerWG)
 {
     size_t perCU = (160 * 1024) / (ldsPerWG ? ldsPerWG : 1);
     if (perCU > ZSA_MAX_WG_PER_CU) perCU = ZSA_MAX_WG_PER_CU;
+    if (const char* e = getenv("ZSA_WG_PER_CU")) { size_t const v = (size_t)atoi(e); if (v >= 1 && v < perCU) perCU = v; }   // tuning knob
     if (perCU < 1) perCU = 1;
     size_t g = (size_t)b->numCU * perCU;
     if (g > b->nFrames) g = b->nFrames;
