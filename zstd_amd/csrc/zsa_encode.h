@@ -40,31 +40,45 @@ struct ZsaCDictDev {            // digested compression dictionary, device resid
     ZsaFseCT ll, of, ml;
 };
 
+#define ZSA_RING_BYTES 4096u   // source ring of the parse stage (zsa_parse.h)
+#ifndef ZSA_NTAGS
+#define ZSA_NTAGS 1024u       // one-byte tags for shared-cell detection
+#endif
 struct ZsaHufNode { u32 count; u16 parent; u8 byte; u8 nbBits; };
-// scratch of the sequence encoder; overlays ZsaEncShared::node (Huffman tree nodes are dead by then)
+// scratch of the stream packers
 struct ZsaSeqEncScratch { u8 code[3][64]; u16 stBits[3][64]; u8 stNb[3][64]; u32 bitbuf[256]; };
 
+// LDS of one compressing workgroup.  Sized for 16 workgroups per CU (160 KiB / 16): the stages of a block reuse the
+// same bytes.  Only the Huffman tables (literal "repeat" mode) and the block-to-block scalars outlive a block; the FSE
+// sequence tables never do at this strategy (set_repeat is only reachable with dictionary tables, which are re-read
+// from the digest: zstd_compress_sequences.c:180-205).
 struct ZsaEncShared {
     ZsaHufCT hufPrev, hufNext;
-    ZsaFseCT ll, of, ml;
+    u32 count[256];                        // histogram of the stage at hand
     union {
-        struct {   // entropy stage of a block
-            u32 count[256];
+        struct {   // Huffman table construction (huf_compress.c:596-766)
             ZsaHufNode node[2 * 256 + 2];
             u16 rpBase[192], rpCurr[192];
-            u8  huffWeight[256];
-            s16 norm[256];
-            u16 cumul[258];
-            u8  tableSymbol[512];
-            // small FSE table for Huffman weights (tableLog <= 6, symbols <= 12)
-            u16 wtNext[64]; s32 wtDfs[16]; u32 wtDnb[16];
-            // batch scratch for the literal gather
-            u32 bLit[64], bSrc[64];
         };
-        struct {   // parse stage of a block (zsa_parse.h): source ring + sequence staging
-            u32 ring[2048 + 4];
+        struct {   // table descriptions, bit packing, sequence tables
+            union {
+                struct {
+                    u8  huffWeight[256];
+                    s16 norm[256];
+                    u16 cumul[258];
+                    u8  tableSymbol[512];
+                    // small FSE table for Huffman weights (tableLog <= 6, symbols <= 12)
+                    u16 wtNext[64]; s32 wtDfs[16]; u32 wtDnb[16];
+                };
+                ZsaSeqEncScratch enc;      // stream packing (Huffman streams, sequence bitstream)
+            };
+            ZsaFseCT ll, of, ml;
+        };
+        struct { u32 bLit[64], bSrc[64]; };   // literal gather
+        struct {   // parse stage (zsa_parse.h): source ring + sequence staging + shared-cell tags
+            u32 ring[ZSA_RING_BYTES / 4 + 4];
             u64 seqStage[64];
-            u8  tags[4096];
+            u8  tags[ZSA_NTAGS];
         };
     };
     // entropy state carried between blocks (zstd_compress_internal.h ZSTD_compressedBlockState_t)
@@ -980,7 +994,7 @@ ZSA_DEV void zsa_hist_bytes(ZsaEncShared* S, const u8* src, u32 n, int lane)
 
 ZSA_DEV u32 zsa_huf_encode_wave(ZsaEncShared* S, u8* dst, const u8* src, u32 srcSize, const ZsaHufCT* ct, int lane)
 {
-    ZsaSeqEncScratch* const E = (ZsaSeqEncScratch*)S->node;
+    ZsaSeqEncScratch* const E = &S->enc;
     for (u32 i = (u32)lane; i < 256; i += ZSA_WAVE) E->bitbuf[i] = 0;
     u32 totalBits = 0, flushedWords = 0;
     wv_lds_fence();
@@ -1339,7 +1353,7 @@ ZSA_DEV u32 zsa_entropyCompress(ZsaEncShared* S, const u64* seq, u32 nbSeq, cons
         // words are flushed to the output together.
         if (lane == 0) *seqHead = (u8)((types[0] << 6) + (types[1] << 4) + (types[2] << 2));
         {
-            ZsaSeqEncScratch* const E = (ZsaSeqEncScratch*)S->node;
+            ZsaSeqEncScratch* const E = &S->enc;
             for (u32 i = (u32)lane; i < 256; i += ZSA_WAVE) E->bitbuf[i] = 0;
             const ZsaFseCT* const myCT = lane == 0 ? &S->of : (lane == 1 ? &S->ml : &S->ll);
             ZsaFseCState st; st.value = 0; st.next = myCT->nextState; st.dfs = myCT->dfs; st.dnb = myCT->dnb; st.stateLog = myCT->tableLog;

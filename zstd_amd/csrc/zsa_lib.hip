@@ -16,8 +16,8 @@
 // ------------------------------------------------------------------------------------------------ kernels
 // One 64-lane workgroup per frame at a time; workgroups pull frame indices from a device counter, so a launch
 // of (CUs x resident workgroups) keeps every CU busy however frame costs vary.
-#ifndef ZSA_ENC_VGPRS
-#define ZSA_ENC_VGPRS 256
+#ifndef ZSA_ENC_WAVES
+#define ZSA_ENC_WAVES 4       // waves per SIMD the compress kernel is register-budgeted for (16 workgroups per CU)
 #endif
 #define ZSA_SEQ_CAP   (ZSA_BLOCKSIZE_MAX / 4 + 64)          // packed sequences per block (zstd_compress.c:1642-1645)
 #define ZSA_LIT_CAP   (ZSA_BLOCKSIZE_MAX + 128)
@@ -52,7 +52,7 @@ zsa_k_decompress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ resu
     if (prof && threadIdx.x == 0) for (int i = 0; i < ZSA_NPROF; i++) atomicAdd((unsigned long long*)&prof[i], (unsigned long long)S.prof[i]);
 }
 
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(ZSA_ENC_VGPRS)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZSA_ENC_WAVES, ZSA_ENC_WAVES)))
 zsa_k_compress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
                u32* __restrict__ counter, u8* __restrict__ scratch, int level, u32 maxHlog, const ZsaCDictDev* cd, u64* __restrict__ prof)
 {
@@ -215,7 +215,7 @@ extern "C" void zsa_batch_free(zsa_batch* b)
     if (b->d_prof) (void)hipFree(b->d_prof);
     free(b);
 }
-#define ZSA_MAX_WG_PER_CU 8
+#define ZSA_MAX_WG_PER_CU 16
 extern "C" zsa_batch* zsa_batch_create(size_t maxFrames)
 {
     int dev = 0;

@@ -24,13 +24,9 @@
 // Included by zsa_encode.h (uses zsa_hash / zsa_packseq / ZsaEncParams from there).
 #pragma once
 
-#define ZSA_RING_BYTES 8192u
-#define ZSA_RING_WORDS (ZSA_RING_BYTES / 4u + 4u)   // + 16 bytes that mirror the first 16, so unaligned reads may run over the end
+// the ring is followed by 16 bytes that mirror its first 16, so unaligned reads may run over the end
 #ifndef ZSA_NP
-#define ZSA_NP 10          // pairs per window: 30 lanes (matches come every ~3 positions on text-like data)
-#endif
-#ifndef ZSA_NTAGS
-#define ZSA_NTAGS 4096u    // one-byte tags for shared-cell detection
+#define ZSA_NP 7           // pairs per window: 21 lanes (matches come every ~3 positions on text-like data)
 #endif
 
 #ifdef ZSA_PARSE_PROF
@@ -203,13 +199,13 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
                 nbSeq++;
                 if ((nbSeq & 63) == 0) { wv_lds_fence(); seqOut[nbSeq - 64 + (u32)lane] = seqStage[lane]; wv_lds_fence(); }
                 anchor = ip0;
-                if (R.hi < ip0 - 2 + 1024 && R.hi < R.limit) zsa_ring_fill(R, ip0 - 2 + 2048, lane);
+                if (R.hi < ip0 - 2 + 512 && R.hi < R.limit) zsa_ring_fill(R, ip0 - 2 + 1024, lane);
             }
             break;
         }
         bool blockDone = false;
         for (;;) {   // one window per iteration
-            {   u32 const want = ip0 - 2 + 2048;
+            {   u32 const want = ip0 - 2 + 1024;
                 if (R.hi < want && R.hi < R.limit) zsa_ring_fill(R, want, lane);
             }
             // ---- positions of this window: P_0 = ip0, P_{i+1} = P_i + s_i, s_{i+1} = step at that time (zstd_fast.c:316-327).
@@ -349,7 +345,7 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
             anchor = ip0;
             ZSA_PPROF(S, lane, 10);
             if (ip0 <= ilimit) {
-                if (R.hi < ip0 - 2 + 1024 && R.hi < R.limit) zsa_ring_fill(R, ip0 - 2 + 2048, lane);
+                if (R.hi < ip0 - 2 + 512 && R.hi < R.limit) zsa_ring_fill(R, ip0 - 2 + 1024, lane);
                 {   // :307-309, in this order
                     u32 const pA = current0 + 2, pB = ip0 - 2;
                     u32 hh = 0;
