@@ -57,7 +57,7 @@ static void dec_entry(void* a)
 extern "C" size_t emu_decompress(void* dst, size_t cap, const void* src, size_t n)
 {
     static ZsaDecShared S;
-    static u8* litBuf = (u8*)malloc(ZSA_BLOCKSIZE_MAX + 64);
+    static u8* litBuf = (u8*)malloc(ZSA_DEC_WKSP_BYTES + 64);
     DecArgs A = { &S, (const u8*)src, n, (u8*)dst, cap, litBuf, nullptr, 0 };
     emu_run_wave(dec_entry, &A);
     return (size_t)A.result;
@@ -143,7 +143,7 @@ extern "C" size_t emu_compress_cdict(void* dst, size_t cap, const void* src, siz
 extern "C" size_t emu_decompress_ddict(void* dst, size_t cap, const void* src, size_t n, const void* h)
 {
     static ZsaDecShared S;
-    static u8* litBuf = (u8*)malloc(ZSA_BLOCKSIZE_MAX + 64);
+    static u8* litBuf = (u8*)malloc(ZSA_DEC_WKSP_BYTES + 64);
     DecArgs A = { &S, (const u8*)src, n, (u8*)dst, cap, litBuf, &((const EmuDDict*)h)->dd, 0 };
     emu_run_wave(dec_entry, &A);
     return (size_t)A.result;

@@ -32,27 +32,40 @@ struct ZsaDDictDev {            // digested dictionary, device resident (zstd_dd
 };
 
 #define ZSA_BITSTAGE 768u    // >= 64 sequences x 89 bits + 8
+// LDS of one decoding workgroup, sized for 12 workgroups per CU: the literal phase of a block (Huffman table) and its
+// sequence phase (three FSE tables) share the same bytes, and so do table construction and batch execution.  Tables a
+// later block may name again ("repeat" modes) are parked in the workgroup's global workspace (ZsaDecBackup).
 struct ZsaDecShared {
-    ZsaSeqCell ll[512], ml[512], of[256];
-    u16 huf[1 << ZSA_HUF_TABLELOG_MAX];
+    union {
+        u16 huf[1 << ZSA_HUF_TABLELOG_MAX];                     // literal phase
+        struct { ZsaSeqCell ll[512], ml[512], of[256]; };        // sequence phase
+    };
     u32 hufLog, llLog, ofLog, mlLog;
-    // table-building scratch
-    u8  weights[256];
-    u16 symStart[256];
-    u16 symbolNext[256];
-    s16 norm[256];
-    u32 fseCell[64];            // weights FSE table: newState | symbol<<16 | nbBits<<24
-    u32 rankVal[ZSA_HUF_TABLELOG_MAX + 2];
-    // one batch of decoded sequences
-    u32 seqLL[64], seqML[64], seqOF[64], outStart[64], litStart[64], mStart[64];
-    // the part of the sequence bitstream the next batch reads (it is consumed downwards), staged by all lanes
-    u8  bits[ZSA_BITSTAGE + 16];
+    union {
+        struct {   // table-building scratch
+            u8  weights[256];
+            u16 symStart[256];
+            u16 symbolNext[256];
+            s16 norm[256];
+            u32 fseCell[64];            // weights FSE table: newState | symbol<<16 | nbBits<<24
+            u32 rankVal[ZSA_HUF_TABLELOG_MAX + 2];
+        };
+        struct {   // one batch of decoded sequences
+            u32 seqLL[64], seqML[64], seqOF[64], outStart[64], litStart[64], mStart[64];
+            // the part of the sequence bitstream the next batch reads (it is consumed downwards), staged by all lanes
+            u8  bits[ZSA_BITSTAGE + 16];
+        };
+    };
     // uniform state published by lane 0
     u64 result;                 // final return value of the frame walk
     u32 err;                    // first error raised inside the current block (0 = none)
     u32 u[16];
     u64 prof[ZSA_NPROF], profLast;
 };
+// per-workgroup global workspace: regenerated literals of the block at hand, then the parked tables
+struct ZsaDecBackup { u16 huf[1 << ZSA_HUF_TABLELOG_MAX]; ZsaSeqCell ll[512], ml[512], of[256]; };
+#define ZSA_DEC_LITBUF_BYTES (ZSA_BLOCKSIZE_MAX + 128u)
+#define ZSA_DEC_WKSP_BYTES   (ZSA_DEC_LITBUF_BYTES + sizeof(ZsaDecBackup))
 enum { ZU_blockType, ZU_lastBlock, ZU_cSize, ZU_origSize, ZU_litMode, ZU_litSize, ZU_litOff, ZU_litCSize,
        ZU_nbSeq, ZU_seqOff, ZU_seqSize, ZU_batchN, ZU_streams, ZU_hufOff, ZU_hufCSize, ZU_tmp };
 
@@ -417,6 +430,7 @@ ZSA_DEV void zsa_raise(ZsaDecShared* S, u32 code) { if (S->err == 0) S->err = co
 ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 srcSize, u32 op, u64 cap,
                              u8* litBuf, int lane)
 {
+    ZsaDecBackup* const bk = (ZsaDecBackup*)(litBuf + ZSA_DEC_LITBUF_BYTES);
     u32 const expectedWriteSize = cap < ZSA_BLOCKSIZE_MAX ? (u32)cap : ZSA_BLOCKSIZE_MAX;
     ZSA_PROF(S, lane, 0);
     // ---- literals header (zstd_decompress_block.c:120-322), lane 0
@@ -485,6 +499,10 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
             if (S->err) return 0;
             if (hSize >= cSrcSize) { if (lane == 0) zsa_raise(S, ZSA_corruption_detected); wv_sync(); return 0; }
             cSrc += hSize; cSrcSize -= hSize;
+            for (u32 i = (u32)lane; i < (1u << S->hufLog); i += ZSA_WAVE) bk->huf[i] = S->huf[i];   // a later block may repeat it
+        } else {   // treeless: the table of an earlier block (or of the dictionary)
+            for (u32 i = (u32)lane; i < (1u << S->hufLog); i += ZSA_WAVE) S->huf[i] = bk->huf[i];
+            wv_sync();
         }
         // streams: huf_decompress.c:543-666
         u32 bad = 0;
@@ -534,6 +552,7 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                 if (!err && ip + 1 > iend) err = ZSA_srcSize_wrong;
                 if (!err) {
                     int const LLtype = *ip >> 6, OFtype = (*ip >> 4) & 3, MLtype = (*ip >> 2) & 3;
+                    S->u[ZU_streams] = (u32)LLtype; S->u[ZU_hufOff] = (u32)OFtype; S->u[ZU_hufCSize] = (u32)MLtype;
                     ip++;
                     ip += zsa_buildSeqTableFromHeader(S, S->ll, &S->llLog, LLtype, 0, ip, (u32)(iend - ip), C.fseEntropy, &err);
                     if (!err) ip += zsa_buildSeqTableFromHeader(S, S->of, &S->ofLog, OFtype, 1, ip, (u32)(iend - ip), C.fseEntropy, &err);
@@ -550,6 +569,16 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
     }
     wv_sync();
     if (S->err) return 0;
+    if (S->u[ZU_nbSeq]) {   // tables built by this block are parked for later "repeat"s; repeated ones come back from there
+        u32 const tLL = S->u[ZU_streams], tOF = S->u[ZU_hufOff], tML = S->u[ZU_hufCSize];
+        if (tLL == zsa_set_repeat) { for (u32 i = (u32)lane; i < (1u << S->llLog); i += ZSA_WAVE) S->ll[i] = bk->ll[i]; }
+        else { for (u32 i = (u32)lane; i < (1u << S->llLog); i += ZSA_WAVE) bk->ll[i] = S->ll[i]; }
+        if (tOF == zsa_set_repeat) { for (u32 i = (u32)lane; i < (1u << S->ofLog); i += ZSA_WAVE) S->of[i] = bk->of[i]; }
+        else { for (u32 i = (u32)lane; i < (1u << S->ofLog); i += ZSA_WAVE) bk->of[i] = S->of[i]; }
+        if (tML == zsa_set_repeat) { for (u32 i = (u32)lane; i < (1u << S->mlLog); i += ZSA_WAVE) S->ml[i] = bk->ml[i]; }
+        else { for (u32 i = (u32)lane; i < (1u << S->mlLog); i += ZSA_WAVE) bk->ml[i] = S->ml[i]; }
+        wv_sync();
+    }
 
     ZSA_PROF(S, lane, 3);
     u32 nbSeq = S->u[ZU_nbSeq];
@@ -753,17 +782,17 @@ ZSA_DEV u64 zsa_xxh64(const u8* p, u64 len)
     return h;
 }
 
-// copy dictionary tables into LDS at frame start (zstd_ddict.c:59-87 ZSTD_copyDDictParameters)
-ZSA_DEV void zsa_load_ddict(ZsaDecShared* S, ZsaDecCtx& C, const ZsaDDictDev* dd, int lane)
+// park the dictionary's tables at frame start (zstd_ddict.c:59-87 ZSTD_copyDDictParameters)
+ZSA_DEV void zsa_load_ddict(ZsaDecShared* S, ZsaDecCtx& C, const ZsaDDictDev* dd, ZsaDecBackup* bk, int lane)
 {
     C.dictContent = dd->content; C.dictSize = dd->contentSize; C.dictID = dd->dictID;
     if (dd->entropyPresent) {
         C.litEntropy = C.fseEntropy = 1;
         C.rep[0] = dd->rep[0]; C.rep[1] = dd->rep[1]; C.rep[2] = dd->rep[2];
-        for (u32 i = (u32)lane; i < (1u << dd->hufLog); i += ZSA_WAVE) S->huf[i] = dd->huf[i];
-        for (u32 i = (u32)lane; i < (1u << dd->llLog); i += ZSA_WAVE) S->ll[i] = dd->ll[i];
-        for (u32 i = (u32)lane; i < (1u << dd->ofLog); i += ZSA_WAVE) S->of[i] = dd->of[i];
-        for (u32 i = (u32)lane; i < (1u << dd->mlLog); i += ZSA_WAVE) S->ml[i] = dd->ml[i];
+        for (u32 i = (u32)lane; i < (1u << dd->hufLog); i += ZSA_WAVE) bk->huf[i] = dd->huf[i];
+        for (u32 i = (u32)lane; i < (1u << dd->llLog); i += ZSA_WAVE) bk->ll[i] = dd->ll[i];
+        for (u32 i = (u32)lane; i < (1u << dd->ofLog); i += ZSA_WAVE) bk->of[i] = dd->of[i];
+        for (u32 i = (u32)lane; i < (1u << dd->mlLog); i += ZSA_WAVE) bk->ml[i] = dd->ml[i];
         if (lane == 0) { S->hufLog = dd->hufLog; S->llLog = dd->llLog; S->ofLog = dd->ofLog; S->mlLog = dd->mlLog; }
     }
     wv_sync();
@@ -835,7 +864,7 @@ ZSA_DEV u64 zsa_decode_frames(ZsaDecShared* S, const u8* src, u64 srcSize, u8* d
         ZsaDecCtx C;
         C.dstBase = dst; C.dictContent = dst; C.dictSize = 0;
         C.rep[0] = 1; C.rep[1] = 4; C.rep[2] = 8; C.litEntropy = C.fseEntropy = 0; C.dictID = 0;
-        if (dd) zsa_load_ddict(S, C, dd, lane);
+        if (dd) zsa_load_ddict(S, C, dd, (ZsaDecBackup*)(litBuf + ZSA_DEC_LITBUF_BYTES), lane);
 
         const u8* ip = src + fhs;
         u64 remaining = srcSize - fhs;

@@ -34,6 +34,7 @@ ZSA_DEV u32 zsa_digest_ddict(ZsaDecShared* S, const u8* dict, u32 dictSize, ZsaD
         pos += h;
     }
     for (u32 i = (u32)lane; i < (1u << S->hufLog); i += ZSA_WAVE) T->huf[i] = S->huf[i];
+    wv_sync();   // the sequence tables are built over the same LDS bytes
     // OF, ML, LL in this order (zstd_decompress.c:1455-1498)
     if (lane == 0) {
         u32 err = 0, p = pos;

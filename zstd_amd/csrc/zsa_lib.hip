@@ -16,6 +16,9 @@
 // ------------------------------------------------------------------------------------------------ kernels
 // One 64-lane workgroup per frame at a time; workgroups pull frame indices from a device counter, so a launch
 // of (CUs x resident workgroups) keeps every CU busy however frame costs vary.
+#ifndef ZSA_DEC_WAVES
+#define ZSA_DEC_WAVES 3       // waves per SIMD the decompress kernel is register-budgeted for (12 workgroups per CU)
+#endif
 #ifndef ZSA_ENC_WAVES
 #define ZSA_ENC_WAVES 4       // waves per SIMD the compress kernel is register-budgeted for (16 workgroups per CU)
 #endif
@@ -25,11 +28,11 @@
 #define ZSA_MAX_HLOG  15
 #define ZSA_HT_BYTES   ((size_t)4 << ZSA_MAX_HLOG)           // hash table of the frame in flight (L2-resident)
 #define ZSA_ENC_SCRATCH_BYTES ((size_t)ZSA_SEQ_CAP * 8 + ZSA_LIT_CAP + ZSA_TMP_CAP + ZSA_HT_BYTES)
-#define ZSA_DEC_SCRATCH_BYTES ((size_t)ZSA_LIT_CAP)
+#define ZSA_DEC_SCRATCH_BYTES ((size_t)((ZSA_DEC_WKSP_BYTES + 255) / 256 * 256))
 
 struct ZsaLaunchDict { const ZsaCDictDev* cd; const ZsaDDictDev* dd; };
 
-__global__ void __launch_bounds__(64, 2)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZSA_DEC_WAVES, ZSA_DEC_WAVES)))
 zsa_k_decompress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
                  u32* __restrict__ counter, u8* __restrict__ scratch, const ZsaDDictDev* dd, u64* __restrict__ prof)
 {
