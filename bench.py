@@ -195,6 +195,7 @@ def main():
         algo_c = bytes_rank + float(total_c)      # compress = srcSize + cSize per frame
         algo_d = float(total_c) + bytes_rank      #              decompress = cSize + dstSize
         wg, lds = enc.last_launch()
+        traffic_c, traffic_d, traffic_src = committed_traffic(N, FS, args.level)
         res = {
             "metric": "GB/s compress & decompress round trip (whole job, uncompressed bytes), 128 KiB frames, level 1; ratio",
             "value": round(bytes_all / elapsed * K / 1e9, 3),
@@ -213,17 +214,32 @@ def main():
             "byte_identical_to_oracle_sample": identical,
             "roofline": {"bound": "hbm", "kernel": "zsa_k_compress", "achieved": round(algo_c / (kc_ms / 1e3) / 1e9, 3),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(algo_c / (kc_ms / 1e3) / 1e9 / HBM_PEAK_GBPS, 6),
-                         "traffic": None, "avg_launch_ms": round(kc_ms, 3), "algorithmic_bytes_per_launch": int(algo_c),
+                         "traffic": traffic_c, "traffic_source": traffic_src, "avg_launch_ms": round(kc_ms, 3), "algorithmic_bytes_per_launch": int(algo_c),
                          "workgroups": wg, "lds_bytes_per_workgroup": lds},
             "roofline_decompress": {"bound": "hbm", "kernel": "zsa_k_decompress", "achieved": round(algo_d / (kd_ms / 1e3) / 1e9, 3),
                                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(algo_d / (kd_ms / 1e3) / 1e9 / HBM_PEAK_GBPS, 6),
-                                    "traffic": None, "avg_launch_ms": round(kd_ms, 3), "algorithmic_bytes_per_launch": int(algo_d)},
+                                    "traffic": traffic_d, "avg_launch_ms": round(kd_ms, 3), "algorithmic_bytes_per_launch": int(algo_d)},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(FS, N, args.seed, args.level)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+# HBM bytes per launch need PMC passes of their own (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE cannot ride along with a
+# timed run); tools/collect_profiles.sh runs them on this very command and tools/summarize_profiles.py commits the
+# per-launch averages, with the guide's gfx950 correction (FETCH_SIZE counts 128-B requests as 64 B: x2), to this file.
+PMC_SUMMARY = "profiles/r01_v8_pmc.json"
+
+
+def committed_traffic(n_frames, frame_bytes, level):
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_SUMMARY)
+    if not (os.path.exists(path) and n_frames == 8192 and frame_bytes == 131072 and level == 1):
+        return None, None, None      # the summary was taken on the default workload only
+    pmc = json.load(open(path))
+    get = lambda k: (int(pmc[k]["hbm_traffic_bytes"]) if k in pmc and "hbm_traffic_bytes" in pmc[k] else None)
+    return get("zsa_k_compress"), get("zsa_k_decompress"), PMC_SUMMARY + " (separate rocprofv3 --pmc passes of this command, per launch)"
 
 
 if __name__ == "__main__":
