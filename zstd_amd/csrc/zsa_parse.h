@@ -50,9 +50,9 @@ ZSA_DEV u64 zsa_ring64(const ZsaRing& R, u32 o) { return ((const ZsaPk64*)(R.b +
 ZSA_DEV u32 zsa_ring32(const ZsaRing& R, u32 o) { return ((const ZsaPk32*)(R.b + (o & (ZSA_RING_BYTES - 1))))->v; }
 ZSA_DEV u32 zsa_ring8(const ZsaRing& R, u32 o) { return R.b[o & (ZSA_RING_BYTES - 1)]; }
 // reads that fall back to global memory (L2) for bytes the ring no longer holds
-ZSA_DEV u32 zsa_rd32(const ZsaRing& R, u32 o) { return (o >= R.lo && o + 4 <= R.hi) ? zsa_ring32(R, o) : wv_ldg32(R.src + o); }
-ZSA_DEV u64 zsa_rd64(const ZsaRing& R, u32 o) { return (o >= R.lo && o + 8 <= R.hi) ? zsa_ring64(R, o) : wv_ldg64(R.src + o); }
-ZSA_DEV u32 zsa_rd8(const ZsaRing& R, u32 o) { return (o >= R.lo && o < R.hi) ? zsa_ring8(R, o) : wv_ldg8(R.src + o); }
+ZSA_DEV u32 zsa_rd32(const ZsaRing& R, u32 o) { return (o >= R.lo && o + 4 <= R.hi) ? zsa_ring32(R, o) : wv_ldg32_now(R.src + o); }
+ZSA_DEV u64 zsa_rd64(const ZsaRing& R, u32 o) { return (o >= R.lo && o + 8 <= R.hi) ? zsa_ring64(R, o) : wv_ldg64_now(R.src + o); }
+ZSA_DEV u32 zsa_rd8(const ZsaRing& R, u32 o) { return (o >= R.lo && o < R.hi) ? zsa_ring8(R, o) : wv_ldg8_now(R.src + o); }
 
 // make [.., min(want, limit)) resident; `want` is uniform
 ZSA_DEV void zsa_ring_fill(ZsaRing& R, u32 want, int lane)
@@ -81,7 +81,10 @@ ZSA_DEV u32 zsa_count_wave(const ZsaRing& R, u32 ip, u32 m, u32 iend, int lane)
     for (;;) {
         u32 const a = ip + total + 8u * (u32)lane, b = m + total + 8u * (u32)lane;
         u32 eq;
-        if (a + 8 <= iend) {
+        if (ip + total + 512 <= iend && ip + total + 512 <= R.hi && m + total >= R.lo) {   // uniform: all 2 x 512 bytes in the ring
+            u64 const diff = zsa_ring64(R, a) ^ zsa_ring64(R, b);
+            eq = diff ? ((u32)__builtin_ctzll(diff) >> 3) : 8;
+        } else if (a + 8 <= iend) {
             u64 const diff = zsa_rd64(R, a) ^ zsa_rd64(R, b);
             eq = diff ? ((u32)__builtin_ctzll(diff) >> 3) : 8;
         } else {
@@ -105,7 +108,16 @@ ZSA_DEV void zsa_extend_wave(const ZsaRing& R, u32 ip, u32 m, u32 iend, u32 ipB,
 {
     bool stop;
     u32 eq = 0;
-    if (lane < 48) {
+    if (ip + 384 <= iend && ip + 384 <= R.hi && mB >= R.lo + 16) {
+        // uniform common case: both compare regions lie in the ring and clear of the block end -- no per-lane paths.
+        // (ring addresses are masked, so the reads of lanes that do not take part are harmless)
+        bool const fw = lane < 48;
+        u32 const k = (u32)lane - 48u;
+        u32 const a = fw ? ip + 8u * (u32)lane : ipB - 1 - k, b = fw ? m + 8u * (u32)lane : mB - 1 - k;
+        u64 const diff = zsa_ring64(R, a) ^ zsa_ring64(R, b);
+        eq = diff ? ((u32)__builtin_ctzll(diff) >> 3) : 8;
+        stop = fw ? eq < 8 : !((k < maxBack) && eq > 0);
+    } else if (lane < 48) {
         u32 const a = ip + 8u * (u32)lane, b = m + 8u * (u32)lane;
         if (a + 8 <= iend) {
             u64 const diff = zsa_rd64(R, a) ^ zsa_rd64(R, b);
@@ -234,7 +246,8 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
             bool const r2lane = chkRep2 && lane == 63;                      // ip0 <= ilimit holds: a window fits
             if (r2lane) { pos = ip0; valid = true; }
             u64 v = 0;
-            if (valid) v = (fast || r2lane) ? zsa_ring64(R, pos - 2) : RD64(pos);
+            if (fast) v = zsa_ring64(R, pos - 2);                           // every lane: masked ring address
+            else if (valid) v = r2lane ? zsa_ring64(R, pos - 2) : RD64(pos);
             u32 h = 0, old = 0;
             if (valid && hashLane) { h = zsa_hashT<MLS>(v, hlog); old = T[h]; tags[h & (ZSA_NTAGS - 1)] = (u8)lane; }
             wv_lds_fence();
@@ -251,7 +264,12 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
             }
             bool const eligible = valid && (r2lane ? true : (role == 0 ? rep1 > 0 : cmpIdx >= prefixStartIndex));
             bool ok = false;
-            if (eligible) ok = RD32(cmpIdx) == (u32)v;
+            {   // ring read by every lane (masked address, always legal); only candidates older than the ring go to L2
+                u32 const co = cmpIdx - 2;
+                u32 cv = zsa_ring32(R, co);
+                if (eligible && !(co >= R.lo && co + 4 <= R.hi)) cv = wv_ldg32_now(R.src + co);
+                ok = eligible && cv == (u32)v;
+            }
             u64 const found = wv_ballot(ok);
             ZSA_PPROF(S, lane, 8);
             u32 const nv = (u32)__builtin_popcountll(vm) >> 1;
@@ -348,11 +366,13 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
                 if (R.hi < ip0 - 2 + 512 && R.hi < R.limit) zsa_ring_fill(R, ip0 - 2 + 1024, lane);
                 {   // :307-309, in this order
                     u32 const pA = current0 + 2, pB = ip0 - 2;
-                    u32 hh = 0;
-                    if (lane < 2) hh = zsa_hashT<MLS>(RD64(lane == 0 ? pA : pB), hlog);
-                    if (lane == 0) T[hh] = pA;
-                    wv_lds_fence();
-                    if (lane == 1) T[hh] = pB;
+                    u32 const pp = lane == 0 ? pA : pB;
+                    u32 hh;
+                    if (pA - 2 >= R.lo && ip0 + 4 <= R.hi) hh = zsa_hashT<MLS>(zsa_ring64(R, pp - 2), hlog);   // uniform
+                    else { hh = 0; if (lane < 2) hh = zsa_hashT<MLS>(RD64(pp), hlog); }
+                    // pA then pB: when both fall into one cell only the later one is stored
+                    bool const sameCell = wv_readlane(hh, 0) == wv_readlane(hh, 1);
+                    if (lane < 2 && !(lane == 0 && sameCell)) T[hh] = pp;
                     wv_lds_fence();
                 }
                 chkRep2 = rep2 > 0;   // :311-324 immediate repcode: evaluated with the next window

@@ -32,6 +32,13 @@ struct __attribute__((packed)) WvPk64 { unsigned long long v; };
 ZSA_DEV unsigned wv_ldg8(const unsigned char* p) { return *(const __attribute__((address_space(1))) unsigned char*)p; }
 ZSA_DEV unsigned wv_ldg32(const unsigned char* p) { return ((const __attribute__((address_space(1))) WvPk32*)p)->v; }
 ZSA_DEV unsigned long long wv_ldg64(const unsigned char* p) { return ((const __attribute__((address_space(1))) WvPk64*)p)->v; }
+// The same loads, completed before control leaves the call.  For the rarely-taken global side of an "LDS or global"
+// read: gfx950 counts loads and stores in one counter (vmcnt), so if a pending load could reach the join of the two
+// sides the compiler must put `s_waitcnt vmcnt(0)` after the join -- and on the common LDS side that wait then stalls on
+// the acknowledgement of whatever stores are still in flight (a full L2 round trip in the middle of the parse chain).
+ZSA_DEV unsigned wv_ldg8_now(const unsigned char* p) { unsigned v = wv_ldg8(p); asm volatile("" : "+v"(v)); return v; }
+ZSA_DEV unsigned wv_ldg32_now(const unsigned char* p) { unsigned v = wv_ldg32(p); asm volatile("" : "+v"(v)); return v; }
+ZSA_DEV unsigned long long wv_ldg64_now(const unsigned char* p) { unsigned long long v = wv_ldg64(p); asm volatile("" : "+v"(v)); return v; }
 ZSA_DEV unsigned long long wv_clock() { return (unsigned long long)clock64(); }
 ZSA_DEV unsigned wv_atomic_add_lds(unsigned* p, unsigned v) { return atomicAdd(p, v); }
 ZSA_DEV unsigned wv_atomic_or_lds(unsigned* p, unsigned v) { return atomicOr(p, v); }
