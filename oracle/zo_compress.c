@@ -1,4 +1,4 @@
-/* zo_compress.c -- oracle: parameter resolution, ZSTD_fast parse, block + frame writer.
+/* zo_compress.c -- oracle: parameter resolution, ZSTD_fast / ZSTD_dfast parses, block + frame writer.
  * TEST INFRASTRUCTURE ONLY (see zo_common.h).
  */
 #include "zo_common.h"
@@ -6,13 +6,13 @@
 #include "zstd_oracle.h"
 
 /* ------------------------------------------------------------------ parameters */
-/* clevels.h:26-131: rows {base for negative levels, 1, 2, 3} of the four size classes.  Levels whose
- * strategy is not ZSTD_fast(1) are outside this oracle's scope and reported as unsupported. */
-static const zo_cparams zo_levelTable[4][4] = {
-    { {19,12,13,1,6,1,1}, {19,13,14,1,7,0,1}, {20,15,16,1,6,0,1}, {21,16,17,1,5,0,2} },   /* > 256 KB */
-    { {18,12,13,1,5,1,1}, {18,13,14,1,6,0,1}, {18,14,14,1,5,0,2}, {18,16,16,1,4,0,2} },   /* <= 256 KB */
-    { {17,12,12,1,5,1,1}, {17,12,13,1,6,0,1}, {17,13,15,1,5,0,1}, {17,15,16,2,5,0,2} },   /* <= 128 KB */
-    { {14,12,13,1,5,1,1}, {14,14,15,1,5,0,1}, {14,14,15,1,4,0,1}, {14,14,15,2,4,0,2} },   /* <= 16 KB */
+/* clevels.h:26-131: rows {base for negative levels, 1, 2, 3, 4} of the four size classes.  Levels whose strategy is
+ * neither ZSTD_fast(1) nor ZSTD_dfast(2) are outside this oracle's scope and reported as unsupported (strat 0 here). */
+static const zo_cparams zo_levelTable[4][5] = {
+    { {19,12,13,1,6,1,1}, {19,13,14,1,7,0,1}, {20,15,16,1,6,0,1}, {21,16,17,1,5,0,2}, {21,18,18,1,5,0,2} },   /* > 256 KB */
+    { {18,12,13,1,5,1,1}, {18,13,14,1,6,0,1}, {18,14,14,1,5,0,2}, {18,16,16,1,4,0,2}, {18,16,17,3,5,2,0} },   /* <= 256 KB */
+    { {17,12,12,1,5,1,1}, {17,12,13,1,6,0,1}, {17,13,15,1,5,0,1}, {17,15,16,2,5,0,2}, {17,17,17,2,4,0,2} },   /* <= 128 KB */
+    { {14,12,13,1,5,1,1}, {14,14,15,1,5,0,1}, {14,14,15,1,4,0,1}, {14,14,15,2,4,0,2}, {14,14,14,4,4,2,0} },   /* <= 16 KB */
 };
 
 /* zstd_compress.c:1427-1451 ZSTD_dictAndWindowLog */
@@ -58,7 +58,7 @@ static zo_cparams zo_adjustCParams(zo_cparams cp, u64 srcSize, size_t dictSize, 
     return cp;
 }
 /* zstd_compress.c:6935-6983 ZSTD_getCParamRowSize + ZSTD_getCParams_internal.
- * Returns 0 and fills *out, or 1 when the level is outside the table kept here (level 0 or > 3). */
+ * Returns 0 and fills *out, or 1 when the level is outside the table kept here (> 4, or a greedy row). */
 int zo_getCParams(zo_cparams* out, int level, u64 srcSizeHint, size_t dictSize, int mode)
 {
     u64 rSize;
@@ -72,9 +72,10 @@ int zo_getCParams(zo_cparams* out, int level, u64 srcSizeHint, size_t dictSize, 
     tableID = (rSize <= 256 * 1024) + (rSize <= 128 * 1024) + (rSize <= 16 * 1024);
     if (level == 0) row = 3;          /* ZSTD_CLEVEL_DEFAULT */
     else if (level < 0) row = 0;
-    else if (level > 3) return 1;
+    else if (level > 4) return 1;
     else row = level;
     {   zo_cparams cp = zo_levelTable[tableID][row];
+        if (cp.strat == 0) return 1;
         if (level < 0) {
             int const minLevel = -(1 << 17);   /* ZSTD_minCLevel() == -ZSTD_TARGETLENGTH_MAX */
             int const clamped = level < minLevel ? minLevel : level;
@@ -92,6 +93,7 @@ typedef struct {
     u32 dictLimit, lowLimit;
     u32 loadedDictEnd;
     u32* hashTable;
+    u32* chainTable;       /* ZSTD_dfast: the short-hash table (zstd_double_fast.c:106) */
     zo_cparams cp;
     const zo_cdict* dms;   /* attached dictionary (dictMatchState), or NULL */
 } zo_matchstate;
@@ -272,6 +274,8 @@ static size_t zo_fast_noDict(zo_matchstate* ms, zo_seqstore* ss, u32 rep[3], con
     rep[1] = rep2 ? rep2 : saved2;
     return (size_t)(iend - anchor);
 }
+
+#include "zo_dfast.inc"
 
 /* ------------------------------------------------------------------ the level-1 parse, attached dictionary */
 /* zstd_fast.c:459-656 ZSTD_compressBlock_fast_dictMatchState_generic (hasStep == 0) */
@@ -636,6 +640,10 @@ static size_t zo_compressFrame(u8* dst, size_t dstCapacity, const u8* src, size_
     }
     ms.cp = cp;
     ms.hashTable = (u32*)calloc((size_t)1 << cp.hlog, sizeof(u32));
+    if (cp.strat == 2) {   /* zstd_compress.c:1941-1943: the chain table exists for every strategy but ZSTD_fast */
+        ms.chainTable = (u32*)calloc((size_t)1 << cp.clog, sizeof(u32));
+        if (!ms.chainTable) { result = ZO_ERR(memory_allocation); goto done; }
+    }
     ss.maxNbSeq = (u32)(blockSize / ((cp.mml == 3) ? 3 : 4)) + 1;
     ss.seq = (zo_seqdef*)malloc((ss.maxNbSeq + 1) * sizeof(zo_seqdef));
     ss.lit = (u8*)malloc(blockSize + 32);
@@ -714,14 +722,15 @@ static size_t zo_compressFrame(u8* dst, size_t dstCapacity, const u8* src, size_
             ss.nbSeq = 0; ss.litSize = 0; ss.longLengthType = 0;
             bsNext->rep[0] = bsPrev->rep[0]; bsNext->rep[1] = bsPrev->rep[1]; bsNext->rep[2] = bsPrev->rep[2];
             /* zstd_compress_internal.h:971-978 ZSTD_matchState_dictMode */
-            if (ms.lowLimit < ms.dictLimit) lastLL = zo_fast_extDict(&ms, &ss, bsNext->rep, ip, blockSize);
+            if (cp.strat == 2)              lastLL = zo_dfast_noDict(&ms, &ss, bsNext->rep, ip, blockSize);   /* no dictionary at this strategy here */
+            else if (ms.lowLimit < ms.dictLimit) lastLL = zo_fast_extDict(&ms, &ss, bsNext->rep, ip, blockSize);
             else if (ms.dms)                lastLL = zo_fast_dictMatchState(&ms, &ss, bsNext->rep, ip, blockSize);
             else                            lastLL = zo_fast_noDict(&ms, &ss, bsNext->rep, ip, blockSize);
             memcpy(ss.lit + ss.litSize, ip + blockSize - lastLL, lastLL);
             ss.litSize += lastLL;
             if (dump) dump(dumpArg, ss.seq, ss.nbSeq, ss.lit, ss.litSize, bsNext->rep);
             cSize = zo_entropyCompressSeqStore(&ss, &bsPrev->entropy, &bsNext->entropy, literalsDisabled,
-                                               op + 3, dstCapacity - 3, blockSize, codeWksp);
+                                               op + 3, dstCapacity - 3, blockSize, codeWksp, (int)cp.strat);
             if (zo_isErr(cSize)) { result = cSize; goto done; }
             if (!isFirstBlock && cSize < 25 && zo_isRLE(ip, blockSize)) { cSize = 1; op[3] = ip[0]; }
         }
@@ -750,7 +759,7 @@ static size_t zo_compressFrame(u8* dst, size_t dstCapacity, const u8* src, size_
     }
     result = (size_t)(op - dst);
 done:
-    free(ms.hashTable); free(ss.seq); free(ss.lit); free(codeWksp); free(bsPrev); free(bsNext);
+    free(ms.hashTable); free(ms.chainTable); free(ss.seq); free(ss.lit); free(codeWksp); free(bsPrev); free(bsNext);
     return result;
 }
 
@@ -767,8 +776,8 @@ size_t zo_compress_dump(void* dst, size_t dstCapacity, const void* src, size_t s
 {
     zo_cparams cp;
     static const u8 empty[8] = {0};
-    if (zo_getCParams(&cp, level, (u64)srcSize, 0, zo_cpm_noAttachDict) || cp.strat != 1)
-        return ZO_ERR(parameter_unsupported);   /* oracle scope: ZSTD_fast levels only */
+    if (zo_getCParams(&cp, level, (u64)srcSize, 0, zo_cpm_noAttachDict) || (cp.strat != 1 && cp.strat != 2))
+        return ZO_ERR(parameter_unsupported);   /* oracle scope: ZSTD_fast and ZSTD_dfast levels only */
     if (srcSize > 0xE0000000u) return ZO_ERR(srcSize_wrong);   /* index overflow correction not restated */
     if (src == NULL) src = empty;
     return zo_compressFrame((u8*)dst, dstCapacity, (const u8*)src, srcSize, cp, NULL, zo_dm_none, dump, dumpArg);

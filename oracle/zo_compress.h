@@ -26,6 +26,6 @@ typedef struct zo_cdict_s {
 } zo_cdict;
 
 size_t zo_entropyCompressSeqStore(const zo_seqstore* ss, const zo_entropy* prev, zo_entropy* next,
-                                  int literalsDisabled, u8* dst, size_t dstCapacity, size_t srcSize, u8* codeWksp);
+                                  int literalsDisabled, u8* dst, size_t dstCapacity, size_t srcSize, u8* codeWksp, int strategy);
 
 #endif

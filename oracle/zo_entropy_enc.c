@@ -733,8 +733,8 @@ static void zo_seqToCodes(const zo_seqstore* ss, u8* llCode, u8* ofCode, u8* mlC
     if (ss->longLengthType == 1) llCode[ss->longLengthPos] = ZO_MaxLL;
     if (ss->longLengthType == 2) mlCode[ss->longLengthPos] = ZO_MaxML;
 }
-/* zstd_compress_sequences.c:157-236 ZSTD_selectEncodingType, strategy ZSTD_fast branch (:180-205) */
-static int zo_selectEncodingType(int* repeatMode, u32 mostFrequent, size_t nbSeq, u32 defaultNormLog, int isDefaultAllowed)
+/* zstd_compress_sequences.c:157-236 ZSTD_selectEncodingType, the `strategy < ZSTD_lazy` branch (:180-205) */
+static int zo_selectEncodingType(int* repeatMode, u32 mostFrequent, size_t nbSeq, u32 defaultNormLog, int isDefaultAllowed, int strategy)
 {
     if (mostFrequent == nbSeq) {
         *repeatMode = zo_rep_none;
@@ -743,7 +743,7 @@ static int zo_selectEncodingType(int* repeatMode, u32 mostFrequent, size_t nbSeq
     }
     if (isDefaultAllowed) {
         size_t const staticFse_nbSeq_max = 1000;
-        size_t const mult = 10 - 1;   /* strategy == ZSTD_fast == 1 */
+        size_t const mult = (size_t)(10 - strategy);   /* :185: ZSTD_fast == 1, ZSTD_dfast == 2 */
         size_t const dynamicFse_nbSeq_min = (((size_t)1 << defaultNormLog) * mult) >> 3;
         if ((*repeatMode == zo_rep_valid) && (nbSeq < staticFse_nbSeq_max)) return zo_set_repeat;
         if ((nbSeq < dynamicFse_nbSeq_min) || (mostFrequent < (nbSeq >> (defaultNormLog - 1)))) {
@@ -822,7 +822,7 @@ static size_t zo_encodeSequences(u8* dst, const zo_seq_ctable* ctML, const u8* m
  * Returns the compressed block body size, 0 for "emit raw", or an error. */
 size_t zo_entropyCompressSeqStore(const zo_seqstore* ss, const zo_entropy* prev, zo_entropy* next,
                                   int literalsDisabled, u8* dst, size_t dstCapacity, size_t srcSize,
-                                  u8* codeWksp /* 3*maxNbSeq bytes */)
+                                  u8* codeWksp /* 3*maxNbSeq bytes */, int strategy /* 1 fast, 2 dfast */)
 {
     u8* const ostart = dst;
     u8* const oend = dst + dstCapacity;
@@ -855,7 +855,7 @@ size_t zo_entropyCompressSeqStore(const zo_seqstore* ss, const zo_entropy* prev,
         {   u32 max = ZO_MaxLL;
             u32 const mostFrequent = zo_hist(count, &max, llCode, nbSeq);
             next->ll_repeat = prev->ll_repeat;
-            LLtype = zo_selectEncodingType(&next->ll_repeat, mostFrequent, nbSeq, ZO_LL_DEFAULTNORMLOG, 1);
+            LLtype = zo_selectEncodingType(&next->ll_repeat, mostFrequent, nbSeq, ZO_LL_DEFAULTNORMLOG, 1, strategy);
             {   size_t const cs = zo_buildSeqCTable(op, (size_t)(oend - op), &next->ll, ZO_LLFSELog, LLtype, count, max, llCode, nbSeq,
                                                     zo_LL_defaultNorm, ZO_LL_DEFAULTNORMLOG, ZO_MaxLL, &prev->ll);
                 if (zo_isErr(cs)) return cs;
@@ -867,7 +867,7 @@ size_t zo_entropyCompressSeqStore(const zo_seqstore* ss, const zo_entropy* prev,
             u32 const mostFrequent = zo_hist(count, &max, ofCode, nbSeq);
             int const defaultAllowed = (max <= ZO_DefaultMaxOff);
             next->of_repeat = prev->of_repeat;
-            OFtype = zo_selectEncodingType(&next->of_repeat, mostFrequent, nbSeq, ZO_OF_DEFAULTNORMLOG, defaultAllowed);
+            OFtype = zo_selectEncodingType(&next->of_repeat, mostFrequent, nbSeq, ZO_OF_DEFAULTNORMLOG, defaultAllowed, strategy);
             {   size_t const cs = zo_buildSeqCTable(op, (size_t)(oend - op), &next->of, ZO_OffFSELog, OFtype, count, max, ofCode, nbSeq,
                                                     zo_OF_defaultNorm, ZO_OF_DEFAULTNORMLOG, ZO_DefaultMaxOff, &prev->of);
                 if (zo_isErr(cs)) return cs;
@@ -878,7 +878,7 @@ size_t zo_entropyCompressSeqStore(const zo_seqstore* ss, const zo_entropy* prev,
         {   u32 max = ZO_MaxML;
             u32 const mostFrequent = zo_hist(count, &max, mlCode, nbSeq);
             next->ml_repeat = prev->ml_repeat;
-            MLtype = zo_selectEncodingType(&next->ml_repeat, mostFrequent, nbSeq, ZO_ML_DEFAULTNORMLOG, 1);
+            MLtype = zo_selectEncodingType(&next->ml_repeat, mostFrequent, nbSeq, ZO_ML_DEFAULTNORMLOG, 1, strategy);
             {   size_t const cs = zo_buildSeqCTable(op, (size_t)(oend - op), &next->ml, ZO_MLFSELog, MLtype, count, max, mlCode, nbSeq,
                                                     zo_ML_defaultNorm, ZO_ML_DEFAULTNORMLOG, ZO_MaxML, &prev->ml);
                 if (zo_isErr(cs)) return cs;

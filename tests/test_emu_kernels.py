@@ -23,6 +23,8 @@ def emu():
     lib.emu_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t] + [ctypes.c_uint] * 4
     lib.emu_decompress.restype = ctypes.c_size_t
     lib.emu_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    lib.emu_compress_level.restype = ctypes.c_size_t
+    lib.emu_compress_level.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
     V, S = ctypes.c_void_p, ctypes.c_size_t
     lib.emu_create_cdict.restype = V; lib.emu_create_cdict.argtypes = [ctypes.c_char_p, S, ctypes.c_int]
     lib.emu_create_ddict.restype = V; lib.emu_create_ddict.argtypes = [ctypes.c_char_p, S]
@@ -94,3 +96,19 @@ def test_emulated_dictionary_path_matches_golden(emu):
     bad = dicts["ref_test_dict"]
     bad = bad[:40] + bytes([bad[40] ^ 0xFF]) + bad[41:60]
     assert not emu.emu_create_cdict(bad, len(bad), 1) and not emu.emu_create_ddict(bad, len(bad))
+
+
+def test_emulated_dfast_parse_matches_oracle(emu, oracle):
+    """zsa_dfast.h (levels 2-4 where the strategy is ZSTD_dfast) through the whole frame encoder"""
+    cases = [b"", b"abc", corpus.frames("json", 1000, 1, 7)[0], corpus.frames("log", 20000, 1, 5)[0], corpus.frames("json", 70000, 1, 3)[0],
+             corpus.frames("log", 140000, 1, 4)[0], bytes(300) + b"xyz" * 500 + bytes(range(256)) * 4]
+    for d in cases:
+        for level in (3, 4, 2, 0):
+            want = oracle.compress(d, level)
+            cap = zstd_amd.CompressBound(len(d))
+            buf = ctypes.create_string_buffer(cap + 1)
+            r = emu.emu_compress_level(buf, cap, d, len(d), level)
+            if isinstance(want, int):
+                assert r == 2 ** 64 + want, (len(d), level)
+            else:
+                assert r == len(want) and buf.raw[:r] == want, (len(d), level)

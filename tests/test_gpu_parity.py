@@ -70,7 +70,7 @@ def test_reference_go_cases(z, oracle):
     assert z.Decompress(bytearray(3), c) == b"Hello World!"          # dst too small: reallocated
     with pytest.raises(z.api.ZstdError):
         z.Decompress(None, b"")                                       # ErrEmptySlice, zstd.go:135-137
-    # levels whose strategy is not ZSTD_fast are outside the engine and say so
+    # levels whose strategy is neither ZSTD_fast nor ZSTD_dfast are outside the engine and say so
     r = z.CompressBatch([b"x" * 100], 5)
     assert isinstance(r[0], z.ErrorCode) and str(r[0]) == "Unsupported parameter"
 
@@ -274,3 +274,38 @@ def test_bulk_small_payload_batch(z, oracle):
     assert all(isinstance(g, bytes) for g in got)
     assert bp.DecompressBatch(got, [1024] * len(frames)) == frames
     assert sum(map(len, got)) < 0.45 * 1024 * 4096
+
+
+def test_dfast_levels_match_golden(z, oracle):
+    """levels 3 and 4 (and 2 at <= 256 KB, 0 = default) -- strategy ZSTD_dfast -- byte-identical to the
+    reference-generated fixture, multi-block frames included (1 MiB at level 3 is BASELINE config 5's chunk)"""
+    from zstd_amd import corpus
+    g = json.load(open(os.path.join(HERE, "golden", "dfast_frames.json")))
+    by_level = {}
+    for k in g["cases"]:
+        by_level.setdefault(k["level"], []).append(k)
+    for level, items in by_level.items():
+        srcs = [bytes.fromhex(k["src_hex"]) for k in items]
+        got = z.CompressBatch(srcs, level)
+        for k, c in zip(items, got):
+            assert isinstance(c, bytes) and c.hex() == k["c_hex"], (k["name"], level)
+        assert z.DecompressBatch(got, [max(len(s), 1) for s in srcs]) == srcs
+    for t in g["tables"]:
+        frames = corpus.frames(t["kind"], t["frame_size"], t["n"], t["seed"])
+        got = z.CompressBatch(frames, t["level"])
+        for c, (clen, chash, _) in zip(got, t["rows"]):
+            assert isinstance(c, bytes) and len(c) == clen and hashlib.sha256(c).hexdigest()[:32] == chash, (t["kind"], t["frame_size"], t["level"])
+        assert z.DecompressBatch(got, [t["frame_size"]] * t["n"]) == frames
+    # one-shot entry point at the Go default-adjacent level, and ragged sizes against the oracle
+    d = corpus.frames("json", 50000, 1, 21)[0]
+    assert z.CompressLevel(None, d, 3) == oracle.compress(d, 3)
+    rnd = random.Random(5)
+    ragged = [corpus.frames("log", rnd.choice([1, 8, 9, 300, 4000, 16384, 16385, 100000, 131073]), 1, 30 + i)[0] for i in range(24)]
+    for level in (3, 4):
+        got = z.CompressBatch(ragged, level)
+        for f, c in zip(ragged, got):
+            want = oracle.compress(f, level)
+            if isinstance(want, int):
+                assert isinstance(c, z.ErrorCode) and str(c) == "Unsupported parameter"   # level 4 is ZSTD_greedy at <= 16 KB
+            else:
+                assert c == want, (len(f), level)

@@ -53,6 +53,27 @@ def test_oracle_matches_golden_corpora(oracle):
             assert oracle.decompress(c, len(f)) == f
 
 
+def _dfast_golden():
+    return json.load(open(os.path.join(HERE, "golden", "dfast_frames.json")))
+
+
+def test_oracle_dfast_matches_golden(oracle):
+    """levels whose strategy is ZSTD_dfast (3, 4, 2 at <= 256 KB, 0 = default): zo_dfast.inc against the reference-generated
+    fixture tests/golden/dfast_frames.json"""
+    g = _dfast_golden()
+    for k in g["cases"]:
+        src = bytes.fromhex(k["src_hex"])
+        c = oracle.compress(src, k["level"])
+        assert isinstance(c, bytes) and c.hex() == k["c_hex"], (k["name"], k["level"])
+        assert oracle.decompress(c, max(len(src), 1)) == src
+    for t in g["tables"]:
+        frames = corpus.frames(t["kind"], t["frame_size"], t["n"], t["seed"])
+        for f, (clen, chash, shash) in zip(frames, t["rows"]):
+            assert hashlib.sha256(f).hexdigest()[:32] == shash, "corpus generator drifted"
+            c = oracle.compress(f, t["level"])
+            assert isinstance(c, bytes) and len(c) == clen and hashlib.sha256(c).hexdigest()[:32] == chash, (t["kind"], t["frame_size"], t["level"])
+
+
 def test_oracle_vs_reference_random(oracle, ref):
     rnd = random.Random(7)
     for trial in range(150):
@@ -65,9 +86,11 @@ def test_oracle_vs_reference_random(oracle, ref):
                           (b"key=%d value=%x\n" % (rnd.randrange(99), rnd.getrandbits(20))) * (m // 16 + 1),
                           bytes(rnd.choice(b"abcde") for _ in range(m))][k])
         d = b"".join(parts)[:n]
-        for level in (1, -2):
+        for level in (1, -2, 3, 4, 2, 0):
             a = ref.compress(d, level)
             b = oracle.compress(d, level)
+            if b == -40 and level == 4:
+                continue   # level 4 is ZSTD_greedy at <= 16 KB and in (128 KB, 256 KB]: outside the oracle
             assert a == b, (trial, n, level)
         assert oracle.decompress(a, max(n, 1)) == d
         assert ref.decompress(b, max(n, 1)) == d

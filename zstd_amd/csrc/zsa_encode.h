@@ -21,7 +21,7 @@
 #include "zsa_common.h"
 #include "zsa_params.h"
 
-struct ZsaEncParams { u32 wlog, hlog, mml, tlen; };
+struct ZsaEncParams { u32 wlog, hlog, mml, tlen, clog, strat; };   // strat: 1 ZSTD_fast, 2 ZSTD_dfast
 
 struct ZsaHufCT { u8 nbBits[256]; u16 val[256]; };
 struct ZsaFseCT { u16 nextState[512]; s32 dfs[ZSA_MaxSeq + 1]; u32 dnb[ZSA_MaxSeq + 1]; u32 tableLog; };
@@ -255,6 +255,7 @@ ZSA_DEV u32 zsa_parse_fast(u32* hashTable, const ZsaEncParams& P, const u8* base
 }
 
 #include "zsa_parse.h"
+#include "zsa_dfast.h"
 
 // zstd_compress_internal.h:780-793 ZSTD_count_2segments
 ZSA_DEV u32 zsa_count_2segments(const u8* ip, const u8* match, const u8* iEnd, const u8* mEnd, const u8* iStart)
@@ -1228,8 +1229,8 @@ ZSA_DEV u32 zsa_MLcode(u32 mlBase)
     if (mlBase < 96) return 40 + ((mlBase - 64) >> 4);
     return 42;
 }
-// zstd_compress_sequences.c:157-236, strategy ZSTD_fast branch; serial
-ZSA_DEV u32 zsa_selectEncodingType(u32* repeatMode, u32 mostFrequent, u32 nbSeq, u32 defaultNormLog, int isDefaultAllowed)
+// zstd_compress_sequences.c:157-236, the `strategy < ZSTD_lazy` branch; serial
+ZSA_DEV u32 zsa_selectEncodingType(u32* repeatMode, u32 mostFrequent, u32 nbSeq, u32 defaultNormLog, int isDefaultAllowed, u32 strategy)
 {
     if (mostFrequent == nbSeq) {
         *repeatMode = zsa_rep_none;
@@ -1237,7 +1238,7 @@ ZSA_DEV u32 zsa_selectEncodingType(u32* repeatMode, u32 mostFrequent, u32 nbSeq,
         return zsa_set_rle;
     }
     if (isDefaultAllowed) {
-        u32 const dynamicFse_nbSeq_min = ((1u << defaultNormLog) * 9) >> 3;
+        u32 const dynamicFse_nbSeq_min = ((1u << defaultNormLog) * (10 - strategy)) >> 3;   // :185
         if ((*repeatMode == zsa_rep_valid) && (nbSeq < 1000)) return zsa_set_repeat;
         if ((nbSeq < dynamicFse_nbSeq_min) || (mostFrequent < (nbSeq >> (defaultNormLog - 1)))) {
             *repeatMode = zsa_rep_none;
@@ -1288,7 +1289,7 @@ ZSA_DEV u32 zsa_buildSeqCTable(ZsaEncShared* S, u8* dst, ZsaFseCT* ct, int kind,
 // Entropy stage of one block: zstd_compress.c:2831-2986.  seq/nbSeq and the gathered literals are in global
 // scratch.  Returns the block body size, 0 for "store raw"; S->err on internal failure.
 ZSA_DEV u32 zsa_entropyCompress(ZsaEncShared* S, const u64* seq, u32 nbSeq, const u8* lit, u32 litSize,
-                                u8* dst, u32 srcSize, u8* tmp, int literalsDisabled, const ZsaCDictDev* cd, int lane)
+                                u8* dst, u32 srcSize, u8* tmp, int literalsDisabled, const ZsaCDictDev* cd, u32 strategy, int lane)
 {
     u8* op = dst;
     {   int const suspect = (nbSeq == 0) || (litSize / nbSeq >= 20);
@@ -1328,7 +1329,7 @@ ZSA_DEV u32 zsa_entropyCompress(ZsaEncShared* S, const u64* seq, u32 nbSeq, cons
                 u32* const rm = kind == 0 ? &S->nextLL : (kind == 1 ? &S->nextOF : &S->nextML);
                 int const defaultAllowed = kind == 1 ? (max <= ZSA_DefaultMaxOff) : 1;
                 u32 const dlog = kind == 1 ? ZSA_OF_DEFAULTNORMLOG : 6;
-                u32 const type = zsa_selectEncodingType(rm, mostFrequent, nbSeq, dlog, defaultAllowed);
+                u32 const type = zsa_selectEncodingType(rm, mostFrequent, nbSeq, dlog, defaultAllowed, strategy);
                 u32 const lastCode = kind == 0 ? zsa_LLcode(zsa_seq_ll(lastSeq)) : (kind == 1 ? zsa_highbit32(zsa_seq_of(lastSeq)) : zsa_MLcode(zsa_seq_ml(lastSeq)));
                 u32 const firstCode = kind == 0 ? zsa_LLcode(zsa_seq_ll(firstSeq)) : (kind == 1 ? zsa_highbit32(zsa_seq_of(firstSeq)) : zsa_MLcode(zsa_seq_ml(firstSeq)));
                 ZsaFseCT* const ct = kind == 0 ? &S->ll : (kind == 1 ? &S->of : &S->ml);
@@ -1529,7 +1530,9 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
     if (cd && dictMode == zsa_dm_copy) {   // ZSTD_copyCDictTableIntoCCtx: tags removed
         for (u32 i = (u32)lane; i < (1u << P.hlog); i += ZSA_WAVE) hashTable[i] = cd->hashTable[i] >> 8;
     } else {
-        for (u32 i = (u32)lane; i < (1u << P.hlog); i += ZSA_WAVE) hashTable[i] = 0;
+        // ZSTD_dfast: the short-hash ("chain") table follows the long one in the same scratch region
+        u32 const cells = (1u << P.hlog) + (P.strat == 2 ? (1u << P.clog) : 0u);
+        for (u32 i = 4u * (u32)lane; i < cells; i += 4u * ZSA_WAVE) { hashTable[i] = 0; hashTable[i + 1] = 0; hashTable[i + 2] = 0; hashTable[i + 3] = 0; }
     }
     if (cd) {
         for (u32 i = (u32)lane; i < 256; i += ZSA_WAVE) { S->hufPrev.nbBits[i] = cd->huf.nbBits[i]; S->hufPrev.val[i] = cd->huf.val[i]; }
@@ -1584,7 +1587,7 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
     {   u64 const ws0 = ((u64)1 << P.wlog) < srcSize ? ((u64)1 << P.wlog) : srcSize;
         blockSize = ws0 < ZSA_BLOCKSIZE_MAX ? (u32)ws0 : ZSA_BLOCKSIZE_MAX;
     }
-    int const literalsDisabled = P.tlen > 0;
+    int const literalsDisabled = (P.strat == 1) && (P.tlen > 0);   // zstd_compress_internal.h:605-618
     u32 const maxDist = 1u << P.wlog;
     u32 remaining = srcSize;
     const u8* ip = src;
@@ -1623,7 +1626,12 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
                 wv_sync();
                 u32 rep[3] = { S->prevRep[0], S->prevRep[1], S->prevRep[2] };
                 u32 lastLL = 0, nbSeq;
-                if (Wn.loadedDictEnd != 0) {   // contiguous-dictionary corner (extDict too small): serial plain parser
+                if (P.strat == 2) {   // ZSTD_dfast (never with a dictionary here): serial for now, zsa_dfast.h
+                    nbSeq = 0;
+                    if (lane == 0) nbSeq = zsa_parse_dfast(hashTable, hashTable + (1u << P.hlog), P, Wn.base, Wn.dictLimit, ip, blockSize, rep, W.seq, &lastLL);
+                    nbSeq = wv_shfl(nbSeq, 0); lastLL = wv_shfl(lastLL, 0);
+                    rep[0] = wv_shfl(rep[0], 0); rep[1] = wv_shfl(rep[1], 0);
+                } else if (Wn.loadedDictEnd != 0) {   // contiguous-dictionary corner (extDict too small): serial plain parser
                     nbSeq = 0;
                     if (lane == 0) nbSeq = zsa_parse_fast(hashTable, P, Wn.base, Wn.dictLimit, Wn.loadedDictEnd, ip, blockSize, rep, W.seq, &lastLL);
                     nbSeq = wv_shfl(nbSeq, 0); lastLL = wv_shfl(lastLL, 0);
@@ -1649,7 +1657,7 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
             zsa_gatherLiterals(S, W.seq, nbSeq, ip, blockSize, lastLL, W.lit, lane);
             wv_sync();
             ZSA_PROF(S, lane, 2);
-            cSize = zsa_entropyCompress(S, W.seq, nbSeq, W.lit, litSize, op + 3, blockSize, W.tmp, literalsDisabled, cd, lane);
+            cSize = zsa_entropyCompress(S, W.seq, nbSeq, W.lit, litSize, op + 3, blockSize, W.tmp, literalsDisabled, cd, P.strat, lane);
             if (S->err) return ZSA_ERR(S->err);
             if (!isFirstBlock && cSize < 25) {   // zstd_compress.c:4258-4269 (ZSTD_isRLE :3413-3433)
                 u32 diff = 0;

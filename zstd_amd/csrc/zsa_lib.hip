@@ -25,8 +25,8 @@
 #define ZSA_SEQ_CAP   (ZSA_BLOCKSIZE_MAX / 4 + 64)          // packed sequences per block (zstd_compress.c:1642-1645)
 #define ZSA_LIT_CAP   (ZSA_BLOCKSIZE_MAX + 128)
 #define ZSA_TMP_CAP   (ZSA_BLOCKSIZE_MAX * 3 / 2 + 512)
-#define ZSA_MAX_HLOG  15
-#define ZSA_HT_BYTES   ((size_t)4 << ZSA_MAX_HLOG)           // hash table of the frame in flight (L2-resident)
+#define ZSA_HT_BYTES   ((size_t)2 << 20)                     // match table(s) of the frame in flight: 4 << hashLog bytes, plus
+                                                            // 4 << chainLog for ZSTD_dfast (level 4 at > 256 KB: 1 MiB + 1 MiB)
 #define ZSA_ENC_SCRATCH_BYTES ((size_t)ZSA_SEQ_CAP * 8 + ZSA_LIT_CAP + ZSA_TMP_CAP + ZSA_HT_BYTES)
 #define ZSA_DEC_SCRATCH_BYTES ((size_t)((ZSA_DEC_WKSP_BYTES + 255) / 256 * 256))
 
@@ -57,7 +57,7 @@ zsa_k_decompress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ resu
 
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZSA_ENC_WAVES, ZSA_ENC_WAVES)))
 zsa_k_compress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
-               u32* __restrict__ counter, u8* __restrict__ scratch, int level, u32 maxHlog, const ZsaCDictDev* cd, u64* __restrict__ prof)
+               u32* __restrict__ counter, u8* __restrict__ scratch, int level, const ZsaCDictDev* cd, u64* __restrict__ prof)
 {
     __shared__ ZsaEncShared S;
     __shared__ u32 nextFrame;
@@ -79,9 +79,11 @@ zsa_k_compress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ result
         int dictMode = zsa_dm_none;
         int const bad = cd ? zsa_resolveCDictUse(&cp, &dictMode, cd->cp, cd->level, cd->dictSize, d.srcSize)
                            : zsa_resolveCParams(&cp, level, d.srcSize, 0, zsa_cpm_noAttachDict);
-        if (bad || cp.strat != 1 || cp.hlog > maxHlog) r = ZSA_ERR(ZSA_parameter_unsupported);
+        // strategies: ZSTD_fast, and ZSTD_dfast without a dictionary; the tables must fit the workgroup's scratch
+        size_t const tableBytes = ((size_t)4 << cp.hlog) + (cp.strat == 2 ? ((size_t)4 << cp.clog) : 0);
+        if (bad || !(cp.strat == 1 || (cp.strat == 2 && !cd)) || tableBytes > ZSA_HT_BYTES) r = ZSA_ERR(ZSA_parameter_unsupported);
         else {
-            ZsaEncParams P; P.wlog = cp.wlog; P.hlog = cp.hlog; P.mml = cp.mml; P.tlen = cp.tlen;
+            ZsaEncParams P; P.wlog = cp.wlog; P.hlog = cp.hlog; P.mml = cp.mml; P.tlen = cp.tlen; P.clog = cp.clog; P.strat = cp.strat;
             r = zsa_encode_frame(&S, zsa_hashTable, P, d.src, d.srcSize, d.dst, d.dstCapacity, W, cd, dictMode);
         }
         if (threadIdx.x == 0) results[f] = r;
@@ -293,18 +295,6 @@ extern "C" size_t zsa_compress_enqueue(zsa_batch* b, int level, const zsa_CDict*
 {
     if (!b) return kErrGeneric;
     if (b->nFrames == 0) return 0;
-    // LDS: hash table of the largest frame in the batch (hashLog depends on the size class, and with a dictionary on
-    // how the dictionary is brought in).  Frames whose table cannot fit report "Unsupported parameter" individually.
-    u32 maxHlog = 6;
-    {   // hashLog is not monotone in srcSize across size classes: take the max over the classes present
-        for (size_t i = 0; i < b->nFrames; i++) {
-            ZsaCParams cp; int mode = 0;
-            int const bad = cdict ? zsa_resolveCDictUse(&cp, &mode, cdict->cp, cdict->level, cdict->dictSize, b->h_frames[i].srcSize)
-                                  : zsa_resolveCParams(&cp, level, b->h_frames[i].srcSize, 0, zsa_cpm_noAttachDict);
-            if (!bad && cp.strat == 1 && cp.hlog > maxHlog) maxHlog = cp.hlog;
-        }
-    }
-    if (maxHlog > ZSA_MAX_HLOG) maxHlog = ZSA_MAX_HLOG;
     size_t const dynLds = 0;
     size_t const ldsPerWG = sizeof(ZsaEncShared) + 64;
     static std::once_flag once;
@@ -312,7 +302,7 @@ extern "C" size_t zsa_compress_enqueue(zsa_batch* b, int level, const zsa_CDict*
     unsigned const grid = zsa_grid(b, ldsPerWG);
     HIPCHK(hipMemsetAsync(b->d_counter, 0, 256, (hipStream_t)stream));
     hipLaunchKernelGGL(zsa_k_compress, dim3(grid), dim3(64), dynLds, (hipStream_t)stream,
-                       b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter, b->d_scratch, level, maxHlog,
+                       b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter, b->d_scratch, level,
                        cdict ? (const ZsaCDictDev*)cdict->d_cd : (const ZsaCDictDev*)nullptr, b->profOn ? b->d_prof : (u64*)nullptr);
     HIPCHK(hipGetLastError());
     b->lastWG = grid; b->lastLDS = (unsigned)ldsPerWG;

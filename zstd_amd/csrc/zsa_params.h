@@ -1,6 +1,6 @@
 // zsa_params.h -- compression-parameter resolution, usable from host and device code.
 // Restates ZSTD_getCParams_internal + ZSTD_adjustCParams_internal (zstd_compress.c:6935-6983, 1427-1555) for the
-// clevels.h rows whose strategy this engine implements (ZSTD_fast).
+// clevels.h rows whose strategy this engine implements (ZSTD_fast, ZSTD_dfast).
 #pragma once
 #include "zsa_common.h"
 
@@ -11,12 +11,12 @@ enum { zsa_cpm_noAttachDict = 0, zsa_cpm_attachDict = 1, zsa_cpm_createCDict = 2
 ZSA_HD u32 zsa_hb32(u32 v) { return 31u - (u32)__builtin_clz(v); }
 
 ZSA_HD ZsaCParams zsa_levelRow(u32 tableID, u32 row)
-{   // clevels.h:26-131, rows {negative-level base, 1, 2, 3}
-    const u8 t[4][4][7] = {
-        { {19,12,13,1,6,1,1}, {19,13,14,1,7,0,1}, {20,15,16,1,6,0,1}, {21,16,17,1,5,0,2} },
-        { {18,12,13,1,5,1,1}, {18,13,14,1,6,0,1}, {18,14,14,1,5,0,2}, {18,16,16,1,4,0,2} },
-        { {17,12,12,1,5,1,1}, {17,12,13,1,6,0,1}, {17,13,15,1,5,0,1}, {17,15,16,2,5,0,2} },
-        { {14,12,13,1,5,1,1}, {14,14,15,1,5,0,1}, {14,14,15,1,4,0,1}, {14,14,15,2,4,0,2} } };
+{   // clevels.h:26-131, rows {negative-level base, 1, 2, 3, 4}; strategy 0 marks a row outside this engine (greedy)
+    const u8 t[4][5][7] = {
+        { {19,12,13,1,6,1,1}, {19,13,14,1,7,0,1}, {20,15,16,1,6,0,1}, {21,16,17,1,5,0,2}, {21,18,18,1,5,0,2} },
+        { {18,12,13,1,5,1,1}, {18,13,14,1,6,0,1}, {18,14,14,1,5,0,2}, {18,16,16,1,4,0,2}, {18,16,17,3,5,2,0} },
+        { {17,12,12,1,5,1,1}, {17,12,13,1,6,0,1}, {17,13,15,1,5,0,1}, {17,15,16,2,5,0,2}, {17,17,17,2,4,0,2} },
+        { {14,12,13,1,5,1,1}, {14,14,15,1,5,0,1}, {14,14,15,1,4,0,1}, {14,14,15,2,4,0,2}, {14,14,14,4,4,2,0} } };
     ZsaCParams c;
     c.wlog = t[tableID][row][0]; c.clog = t[tableID][row][1]; c.hlog = t[tableID][row][2]; c.slog = t[tableID][row][3];
     c.mml = t[tableID][row][4]; c.tlen = t[tableID][row][5]; c.strat = t[tableID][row][6];
@@ -62,8 +62,9 @@ ZSA_HD int zsa_resolveCParams(ZsaCParams* out, int level, u64 srcSizeHint, u64 d
     }
     u32 const tableID = (rSize <= 256 * 1024) + (rSize <= 128 * 1024) + (rSize <= 16 * 1024);
     u32 row;
-    if (level == 0) row = 3; else if (level < 0) row = 0; else if (level > 3) return 1; else row = (u32)level;
+    if (level == 0) row = 3; else if (level < 0) row = 0; else if (level > 4) return 1; else row = (u32)level;
     ZsaCParams cp = zsa_levelRow(tableID, row);
+    if (cp.strat == 0) return 1;
     if (level < 0) { int const minLevel = -(1 << 17); int const cl = level < minLevel ? minLevel : level; cp.tlen = (u32)(-cl); }
     *out = zsa_adjustCParams(cp, srcSizeHint, dictSize, mode);
     return 0;
