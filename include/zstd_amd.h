@@ -5,8 +5,10 @@
  * count or (size_t)-ZSTD_ErrorCode; zsa_isError()/zsa_getErrorName() give the same answers and strings as the
  * reference's ZSTD_isError()/ZSTD_getErrorName() (errors.go:21-34 string-matches them).
  *
- * Scope of the engine: level-1-class compression (strategy ZSTD_fast: level 1 at every size, level 2 and
- * negative levels where clevels.h selects ZSTD_fast), byte-identical to libzstd 1.5.5; decompression of any
+ * Scope of the engine: compression at the levels whose strategy is ZSTD_fast (level 1 and the negative levels at every
+ * size, level 2 above 256 KB and up to 128 KB) or ZSTD_dfast (levels 3 and 0 at every size, level 4 except at <= 16 KB
+ * and in (128 KB, 256 KB], level 2 in (128 KB, 256 KB]; without a dictionary), byte-identical to libzstd 1.5.5;
+ * dictionary compression (CDict) at the ZSTD_fast levels; decompression of any
  * Zstandard frame (concatenated and skippable frames, checksums, dictionaries) except legacy v0.x frames.
  * Anything else returns an error code -- there is no CPU fallback inside this library: every entry point
  * that moves data runs on the GPU and fails loudly when no HIP device is usable.
