@@ -32,6 +32,9 @@ struct __attribute__((packed)) WvPk64 { unsigned long long v; };
 ZSA_DEV unsigned wv_ldg8(const unsigned char* p) { return *(const __attribute__((address_space(1))) unsigned char*)p; }
 ZSA_DEV unsigned wv_ldg32(const unsigned char* p) { return ((const __attribute__((address_space(1))) WvPk32*)p)->v; }
 ZSA_DEV unsigned long long wv_ldg64(const unsigned char* p) { return ((const __attribute__((address_space(1))) WvPk64*)p)->v; }
+// aligned table cells in global memory
+ZSA_DEV unsigned wv_ldg_cell(const unsigned* p) { return *(const __attribute__((address_space(1))) unsigned*)p; }
+ZSA_DEV void wv_stg_cell(unsigned* p, unsigned v) { *(__attribute__((address_space(1))) unsigned*)p = v; }
 // The same loads, completed before control leaves the call.  For the rarely-taken global side of an "LDS or global"
 // read: gfx950 counts loads and stores in one counter (vmcnt), so if a pending load could reach the join of the two
 // sides the compiler must put `s_waitcnt vmcnt(0)` after the join -- and on the common LDS side that wait then stalls on
