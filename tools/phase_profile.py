@@ -4,19 +4,28 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, zstd_amd
 from zstd_amd import corpus
+# usage: phase_profile.py [frames [frame_bytes [kind [level [dict]]]]]   (dict: name of a fixture dictionary in tests/golden/dict_cases.json)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-FS = 131072
-host = corpus.generate("log", FS, N, 42, threads=16)
+FS = int(sys.argv[2]) if len(sys.argv) > 2 else 131072
+KIND = sys.argv[3] if len(sys.argv) > 3 else "log"
+LEVEL = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+CD = DD = None
+if len(sys.argv) > 5:
+    import base64, json
+    g = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "dict_cases.json")))
+    BP = zstd_amd.NewBulkProcessor(base64.b64decode(g["dicts"][sys.argv[5]]["b64"]), LEVEL)
+    CD, DD = BP.cDict, BP.dDict
+host = corpus.generate(KIND, FS, N, 42, threads=16)
 src = torch.from_numpy(host).cuda()
 bound = zstd_amd.CompressBound(FS); stride = (bound + 255) // 256 * 256
 cbuf = torch.empty(N * stride, dtype=torch.uint8, device="cuda"); out = torch.empty(N * FS, dtype=torch.uint8, device="cuda")
 enc, dec = zstd_amd.DeviceBatch(N), zstd_amd.DeviceBatch(N)
 enc.set_frames_strided(N, src.data_ptr(), FS, None, cbuf.data_ptr(), stride, bound)
 dec.set_frames_strided(N, cbuf.data_ptr(), stride, None, out.data_ptr(), FS, FS)
-enc.compress(1); dec.link_src_sizes(enc); dec.decompress(); torch.cuda.synchronize()
+enc.compress(LEVEL, CD); dec.link_src_sizes(enc); dec.decompress(DD); torch.cuda.synchronize()
 ENC = ["init/hdr", "parse (rest: post-match, rep2, ring)", "gather lits", "lit stats+huf build", "huf encode", "seq hist+tables", "seq encode", "finalize", "parse: window eval", "parse: winner+table", "parse: extension+store", "fetch work"]
 DEC = ["blk hdr/other", "huf table", "huf streams", "seq tables", "seq decode", "exec literals", "exec matches", "last lits", "", "", "", "fetch work"]
-for name, b, fn, labels in (("compress", enc, lambda: enc.compress(1), ENC), ("decompress", dec, lambda: dec.decompress(), DEC)):
+for name, b, fn, labels in (("compress", enc, lambda: enc.compress(LEVEL, CD), ENC), ("decompress", dec, lambda: dec.decompress(DD), DEC)):
     b.profile(True)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); fn(); e1.record(); torch.cuda.synchronize()

@@ -35,7 +35,7 @@ struct ZsaDDictDev {            // digested dictionary, device resident (zstd_dd
 // LDS of one decoding workgroup, sized for 12 workgroups per CU: the literal phase of a block (Huffman table) and its
 // sequence phase (three FSE tables) share the same bytes, and so do table construction and batch execution.  Tables a
 // later block may name again ("repeat" modes) are parked in the workgroup's global workspace (ZsaDecBackup).
-struct ZsaDecShared {
+struct __attribute__((aligned(16))) ZsaDecShared {
     union {
         u16 huf[1 << ZSA_HUF_TABLELOG_MAX];                     // literal phase
         struct { ZsaSeqCell ll[512], ml[512], of[256]; };        // sequence phase
@@ -63,7 +63,7 @@ struct ZsaDecShared {
     u64 prof[ZSA_NPROF], profLast;
 };
 // per-workgroup global workspace: regenerated literals of the block at hand, then the parked tables
-struct ZsaDecBackup { u16 huf[1 << ZSA_HUF_TABLELOG_MAX]; ZsaSeqCell ll[512], ml[512], of[256]; };
+struct __attribute__((aligned(16))) ZsaDecBackup { u16 huf[1 << ZSA_HUF_TABLELOG_MAX]; ZsaSeqCell ll[512], ml[512], of[256]; };
 #define ZSA_DEC_LITBUF_BYTES (ZSA_BLOCKSIZE_MAX + 128u)
 #define ZSA_DEC_WKSP_BYTES   (ZSA_DEC_LITBUF_BYTES + sizeof(ZsaDecBackup))
 enum { ZU_blockType, ZU_lastBlock, ZU_cSize, ZU_origSize, ZU_litMode, ZU_litSize, ZU_litOff, ZU_litCSize,
@@ -421,7 +421,18 @@ struct ZsaDecCtx {
     u32 rep[3];
     int litEntropy, fseEntropy;
     u32 dictID;
+    // where the tables a later block may name again ("repeat" / treeless) currently live: the dictionary's digest until
+    // a block of this frame builds its own, then the workgroup's workspace (ZsaDecBackup)
+    const u16* hufSrc; const ZsaSeqCell* llSrc; const ZsaSeqCell* ofSrc; const ZsaSeqCell* mlSrc;
 };
+
+// table moves between LDS and global memory, 16 bytes per lane and step (all tables are 16-byte aligned and padded)
+struct __attribute__((aligned(16))) ZsaV16 { u32 a, b, c, d; };
+ZSA_DEV void zsa_copy16(void* dst, const void* src, u32 bytes, int lane)
+{
+    u32 const n = (bytes + 15u) >> 4;
+    for (u32 i = (u32)lane; i < n; i += ZSA_WAVE) ((ZsaV16*)dst)[i] = ((const ZsaV16*)src)[i];
+}
 
 ZSA_DEV void zsa_raise(ZsaDecShared* S, u32 code) { if (S->err == 0) S->err = code; }
 
@@ -499,9 +510,10 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
             if (S->err) return 0;
             if (hSize >= cSrcSize) { if (lane == 0) zsa_raise(S, ZSA_corruption_detected); wv_sync(); return 0; }
             cSrc += hSize; cSrcSize -= hSize;
-            for (u32 i = (u32)lane; i < (1u << S->hufLog); i += ZSA_WAVE) bk->huf[i] = S->huf[i];   // a later block may repeat it
+            zsa_copy16(bk->huf, S->huf, 2u << S->hufLog, lane);   // a later block may repeat it
+            C.hufSrc = bk->huf;
         } else {   // treeless: the table of an earlier block (or of the dictionary)
-            for (u32 i = (u32)lane; i < (1u << S->hufLog); i += ZSA_WAVE) S->huf[i] = bk->huf[i];
+            zsa_copy16(S->huf, C.hufSrc, 2u << S->hufLog, lane);
             wv_sync();
         }
         // streams: huf_decompress.c:543-666
@@ -571,12 +583,12 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
     if (S->err) return 0;
     if (S->u[ZU_nbSeq]) {   // tables built by this block are parked for later "repeat"s; repeated ones come back from there
         u32 const tLL = S->u[ZU_streams], tOF = S->u[ZU_hufOff], tML = S->u[ZU_hufCSize];
-        if (tLL == zsa_set_repeat) { for (u32 i = (u32)lane; i < (1u << S->llLog); i += ZSA_WAVE) S->ll[i] = bk->ll[i]; }
-        else { for (u32 i = (u32)lane; i < (1u << S->llLog); i += ZSA_WAVE) bk->ll[i] = S->ll[i]; }
-        if (tOF == zsa_set_repeat) { for (u32 i = (u32)lane; i < (1u << S->ofLog); i += ZSA_WAVE) S->of[i] = bk->of[i]; }
-        else { for (u32 i = (u32)lane; i < (1u << S->ofLog); i += ZSA_WAVE) bk->of[i] = S->of[i]; }
-        if (tML == zsa_set_repeat) { for (u32 i = (u32)lane; i < (1u << S->mlLog); i += ZSA_WAVE) S->ml[i] = bk->ml[i]; }
-        else { for (u32 i = (u32)lane; i < (1u << S->mlLog); i += ZSA_WAVE) bk->ml[i] = S->ml[i]; }
+        if (tLL == zsa_set_repeat) zsa_copy16(S->ll, C.llSrc, 8u << S->llLog, lane);
+        else { zsa_copy16(bk->ll, S->ll, 8u << S->llLog, lane); C.llSrc = bk->ll; }
+        if (tOF == zsa_set_repeat) zsa_copy16(S->of, C.ofSrc, 8u << S->ofLog, lane);
+        else { zsa_copy16(bk->of, S->of, 8u << S->ofLog, lane); C.ofSrc = bk->of; }
+        if (tML == zsa_set_repeat) zsa_copy16(S->ml, C.mlSrc, 8u << S->mlLog, lane);
+        else { zsa_copy16(bk->ml, S->ml, 8u << S->mlLog, lane); C.mlSrc = bk->ml; }
         wv_sync();
     }
 
@@ -782,17 +794,14 @@ ZSA_DEV u64 zsa_xxh64(const u8* p, u64 len)
     return h;
 }
 
-// park the dictionary's tables at frame start (zstd_ddict.c:59-87 ZSTD_copyDDictParameters)
+// point the frame at the dictionary's tables (zstd_ddict.c:59-87 ZSTD_copyDDictParameters)
 ZSA_DEV void zsa_load_ddict(ZsaDecShared* S, ZsaDecCtx& C, const ZsaDDictDev* dd, ZsaDecBackup* bk, int lane)
 {
     C.dictContent = dd->content; C.dictSize = dd->contentSize; C.dictID = dd->dictID;
     if (dd->entropyPresent) {
         C.litEntropy = C.fseEntropy = 1;
         C.rep[0] = dd->rep[0]; C.rep[1] = dd->rep[1]; C.rep[2] = dd->rep[2];
-        for (u32 i = (u32)lane; i < (1u << dd->hufLog); i += ZSA_WAVE) bk->huf[i] = dd->huf[i];
-        for (u32 i = (u32)lane; i < (1u << dd->llLog); i += ZSA_WAVE) bk->ll[i] = dd->ll[i];
-        for (u32 i = (u32)lane; i < (1u << dd->ofLog); i += ZSA_WAVE) bk->of[i] = dd->of[i];
-        for (u32 i = (u32)lane; i < (1u << dd->mlLog); i += ZSA_WAVE) bk->ml[i] = dd->ml[i];
+        C.hufSrc = dd->huf; C.llSrc = dd->ll; C.ofSrc = dd->of; C.mlSrc = dd->ml;   // shared, read-only: nothing is copied per frame
         if (lane == 0) { S->hufLog = dd->hufLog; S->llLog = dd->llLog; S->ofLog = dd->ofLog; S->mlLog = dd->mlLog; }
     }
     wv_sync();
@@ -864,6 +873,9 @@ ZSA_DEV u64 zsa_decode_frames(ZsaDecShared* S, const u8* src, u64 srcSize, u8* d
         ZsaDecCtx C;
         C.dstBase = dst; C.dictContent = dst; C.dictSize = 0;
         C.rep[0] = 1; C.rep[1] = 4; C.rep[2] = 8; C.litEntropy = C.fseEntropy = 0; C.dictID = 0;
+        {   ZsaDecBackup* const bk0 = (ZsaDecBackup*)(litBuf + ZSA_DEC_LITBUF_BYTES);
+            C.hufSrc = bk0->huf; C.llSrc = bk0->ll; C.ofSrc = bk0->of; C.mlSrc = bk0->ml;
+        }
         if (dd) zsa_load_ddict(S, C, dd, (ZsaDecBackup*)(litBuf + ZSA_DEC_LITBUF_BYTES), lane);
 
         const u8* ip = src + fhs;

@@ -10,7 +10,7 @@
 #include "zsa_decode.h"
 #include "zsa_encode.h"
 
-struct ZsaDDictTables { u16 huf[1 << ZSA_HUF_TABLELOG_MAX]; ZsaSeqCell ll[512], of[256], ml[512]; };
+struct __attribute__((aligned(16))) ZsaDDictTables { u16 huf[1 << ZSA_HUF_TABLELOG_MAX]; ZsaSeqCell ll[512], of[256], ml[512]; };
 
 // Returns 0, or an error code (uniform).  `dict` is device memory that outlives the digest.
 ZSA_DEV u32 zsa_digest_ddict(ZsaDecShared* S, const u8* dict, u32 dictSize, ZsaDDictDev* out, ZsaDDictTables* T)
