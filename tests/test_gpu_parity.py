@@ -309,3 +309,41 @@ def test_dfast_levels_match_golden(z, oracle):
                 assert isinstance(c, z.ErrorCode) and str(c) == "Unsupported parameter"   # level 4 is ZSTD_greedy at <= 16 KB
             else:
                 assert c == want, (len(f), level)
+
+
+def test_ctx_go_cases(z, oracle):
+    # zstd_ctx_test.go:9-40 (round trip, Decompress with a too-small dst), :42-66 (levels), :75-119 (empty input / output),
+    # :121-142 (130 KB payload into a short dst)
+    c = z.NewCtx()
+    hello = b"Hello World!"
+    comp = c.CompressLevel(None, hello, 1)
+    assert comp == oracle.compress(hello, 1)
+    assert c.Decompress(None, comp) == hello and c.Decompress(bytearray(2), comp) == hello
+    for level in (1, 2, 3, 4):
+        for size in (1, 10, 100, 1000, 100000):
+            d = bytes((i * 7 + (i >> 3)) & 0xFF for i in range(size))
+            want = oracle.compress(d, level)
+            if isinstance(want, int):
+                continue      # level 4 below 16 KB is ZSTD_greedy
+            got = c.CompressLevel(bytearray(z.CompressBound(size)), d, level)
+            assert bytes(got) == want and c.Decompress(None, bytes(got)) == d
+    e = c.CompressLevel(None, b"", 1)
+    assert e == oracle.compress(b"", 1) and c.Decompress(None, e) == b""
+    with pytest.raises(z.api.ZstdError):
+        c.Decompress(None, b"")
+    big = bytes(130 * 1024)
+    assert c.Decompress(bytearray(1), c.CompressLevel(None, big, 1)) == big
+    with pytest.raises(z.api.ZstdError):          # DefaultCompression (5) is ZSTD_greedy: code 40, the Go shim keeps the vendored C
+        c.Compress(None, hello)
+
+
+def test_bulk_destination_cases(z, oracle):
+    # zstd_bullk_test.go:128-141, 143-156 (Compress into a given / a too-small destination), :158-168, 170-180 (Decompress)
+    import base64
+    from golden_inputs import REF_TEST_DICT_B64, REF_TEST_PAYLOAD
+    bp = z.NewBulkProcessor(base64.b64decode(REF_TEST_DICT_B64), z.BestSpeed)
+    want = bp.Compress(None, REF_TEST_PAYLOAD)
+    assert bp.Compress(bytearray(z.CompressBound(len(REF_TEST_PAYLOAD))), REF_TEST_PAYLOAD) == want
+    assert bp.Compress(bytearray(1), REF_TEST_PAYLOAD) == want                  # dst too small: a new buffer is used
+    assert bp.Decompress(bytearray(len(REF_TEST_PAYLOAD)), want) == REF_TEST_PAYLOAD
+    assert bp.Decompress(bytearray(1), want) == REF_TEST_PAYLOAD                # dst too small: sized from the frame header

@@ -7,6 +7,6 @@ from .api import (  # noqa: F401
     BestSpeed, BestCompression, DefaultCompression,
     ErrEmptySlice, ErrEmptyDictionary, ErrBadDictionary, ErrorCode,
     CompressBound, Compress, CompressLevel, Decompress, DecompressInto,
-    IsDstSizeTooSmallError, BulkProcessor, NewBulkProcessor,
+    IsDstSizeTooSmallError, BulkProcessor, NewBulkProcessor, NewCtx,
     CompressBatch, DecompressBatch, DeviceBatch, getCParams,
 )

@@ -183,6 +183,27 @@ def DecompressBatch(srcs, caps=None, ddict=None):
     return _batch_call(lib.zsa_decompress_batch, srcs, caps, (ddict,))
 
 
+class ctx:
+    """zstd_ctx.go:38-131 -- the reusable-context flavour of the one-shot API.  libzstd contexts carry nothing from one
+    one-shot call to the next that changes the result ("first and later CCtx usages compress the same"), so the engine needs
+    no per-context state: the methods run the same entry points (zstd_ctx.go:70,78 ZSTD_compressCCtx -> zsa_compress,
+    :107 ZSTD_decompressDCtx -> zsa_decompress) with the same dst-reuse and fallback rules."""
+
+    def Compress(self, dst, src):
+        return self.CompressLevel(dst, src, DefaultCompression)        # zstd_ctx.go:53-55
+
+    def CompressLevel(self, dst, src, level):
+        return CompressLevel(dst, src, level)                          # zstd_ctx.go:57-91
+
+    def Decompress(self, dst, src):
+        return Decompress(dst, src)                                    # zstd_ctx.go:93-126
+
+
+def NewCtx():
+    """zstd_ctx.go:43-51."""
+    return ctx()
+
+
 class BulkProcessor:
     """zstd_bulk.go:27-151."""
 
