@@ -40,7 +40,9 @@ struct ZsaCDictDev {            // digested compression dictionary, device resid
     ZsaFseCT ll, of, ml;
 };
 
+#ifndef ZSA_RING_BYTES
 #define ZSA_RING_BYTES 4096u   // source ring of the parse stage (zsa_parse.h)
+#endif
 #ifndef ZSA_NTAGS
 #define ZSA_NTAGS 1024u       // one-byte tags for shared-cell detection
 #endif

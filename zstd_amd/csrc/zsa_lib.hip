@@ -25,8 +25,10 @@
 #define ZSA_SEQ_CAP   (ZSA_BLOCKSIZE_MAX / 4 + 64)          // packed sequences per block (zstd_compress.c:1642-1645)
 #define ZSA_LIT_CAP   (ZSA_BLOCKSIZE_MAX + 128)
 #define ZSA_TMP_CAP   (ZSA_BLOCKSIZE_MAX * 3 / 2 + 512)
+#ifndef ZSA_HT_BYTES
 #define ZSA_HT_BYTES   ((size_t)2 << 20)                     // match table(s) of the frame in flight: 4 << hashLog bytes, plus
                                                             // 4 << chainLog for ZSTD_dfast (level 4 at > 256 KB: 1 MiB + 1 MiB)
+#endif
 #define ZSA_ENC_SCRATCH_BYTES ((size_t)ZSA_SEQ_CAP * 8 + ZSA_LIT_CAP + ZSA_TMP_CAP + ZSA_HT_BYTES)
 #define ZSA_DEC_SCRATCH_BYTES ((size_t)((ZSA_DEC_WKSP_BYTES + 255) / 256 * 256))
 
@@ -220,7 +222,9 @@ extern "C" void zsa_batch_free(zsa_batch* b)
     if (b->d_prof) (void)hipFree(b->d_prof);
     free(b);
 }
+#ifndef ZSA_MAX_WG_PER_CU
 #define ZSA_MAX_WG_PER_CU 16
+#endif
 extern "C" zsa_batch* zsa_batch_create(size_t maxFrames)
 {
     int dev = 0;

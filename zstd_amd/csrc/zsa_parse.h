@@ -195,6 +195,9 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
     // The immediate-repcode check that follows every match (zstd_fast.c:311-324) rides along with the next window as one
     // more event (lane 63) that precedes all others: its compare shares the window's memory round trip.
     bool chkRep2 = false;
+    // The source words of the first window after a match are requested as soon as the match end is known, so that their
+    // LDS round trip overlaps with the post-match table inserts instead of following them.
+    u64 vPre = 0; bool havePre = false;
     for (;;) {   // one search episode per iteration (label _start)
         u32 step = stepSize, nextStep = ip0 + 128, sNext = stepSize;
         if (ip0 + step + 1 >= ilimit) {
@@ -246,8 +249,9 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
             bool const r2lane = chkRep2 && lane == 63;                      // ip0 <= ilimit holds: a window fits
             if (r2lane) { pos = ip0; valid = true; }
             u64 v = 0;
-            if (fast) v = zsa_ring64(R, pos - 2);                           // every lane: masked ring address
+            if (fast) v = havePre ? vPre : zsa_ring64(R, pos - 2);          // every lane: masked ring address
             else if (valid) v = r2lane ? zsa_ring64(R, pos - 2) : RD64(pos);
+            havePre = false;
             u32 h = 0, old = 0;
             if (valid && hashLane) { h = zsa_hashT<MLS>(v, hlog); old = T[h]; tags[h & (ZSA_NTAGS - 1)] = (u8)lane; }
             wv_lds_fence();
@@ -286,6 +290,10 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
                 if ((nbSeq & 63) == 0) { wv_lds_fence(); seqOut[nbSeq - 64 + (u32)lane] = seqStage[lane]; wv_lds_fence(); }
                 anchor = ip0;
                 chkRep2 = (ip0 <= ilimit) && rep2 > 0;
+                if (stepSize == 2 && ip0 + 3 < ilimit) {
+                    if (R.hi < ip0 - 2 + 512 && R.hi < R.limit) zsa_ring_fill(R, ip0 - 2 + 1024, lane);
+                    vPre = zsa_ring64(R, ((chkRep2 && lane == 63) ? ip0 : ip0 + fastOff) - 2); havePre = true;
+                }
                 ZSA_PPROF(S, lane, 10);
                 break;   // back to _start with the new ip0
             }
@@ -364,6 +372,9 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
             ZSA_PPROF(S, lane, 10);
             if (ip0 <= ilimit) {
                 if (R.hi < ip0 - 2 + 512 && R.hi < R.limit) zsa_ring_fill(R, ip0 - 2 + 1024, lane);
+                if (stepSize == 2 && ip0 + 3 < ilimit) {   // first window of the next search: step 2, positions ip0 + fastOff
+                    vPre = zsa_ring64(R, ((rep2 > 0 && lane == 63) ? ip0 : ip0 + fastOff) - 2); havePre = true;
+                }
                 {   // :307-309, in this order
                     u32 const pA = current0 + 2, pB = ip0 - 2;
                     u32 const pp = lane == 0 ? pA : pB;
