@@ -112,3 +112,26 @@ def test_emulated_dfast_parse_matches_oracle(emu, oracle):
                 assert r == 2 ** 64 + want, (len(d), level)
             else:
                 assert r == len(want) and buf.raw[:r] == want, (len(d), level)
+
+
+def test_emulated_fingerprint_collisions(oracle):
+    """zsa_parse.h keeps a fingerprint of the 4 bytes at each position in the spare bits of a match-table cell and only
+    reads a candidate's bytes when it wins its window; with 2-bit fingerprints (test build) one probe in four collides,
+    which drives the take-the-next-event path.  Output must not change."""
+    d = os.path.join(ROOT, "tests", "emu")
+    subprocess.run(["make", "-s", "-C", d, os.path.join(d, "libzsa_emu_fp2.so")], check=True)
+    lib = ctypes.CDLL(os.path.join(d, "libzsa_emu_fp2.so"))
+    lib.emu_compress_level.restype = ctypes.c_size_t
+    lib.emu_compress_level.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
+    rnd = random.Random(9)
+    cases = [corpus.frames("log", 40000, 1, 5)[0], corpus.frames("json", 131073, 1, 6)[0], corpus.frames("log", 300000, 1, 7)[0],
+             bytes(rnd.choice(b"abcde") for _ in range(30000)) + b"ab" * 3000 + bytes(5000)]
+    for data in cases:
+        for level in (1, -3, 2):
+            want = oracle.compress(data, level)
+            if isinstance(want, int):
+                continue
+            cap = zstd_amd.CompressBound(len(data))
+            buf = ctypes.create_string_buffer(cap + 1)
+            r = lib.emu_compress_level(buf, cap, data, len(data), level)
+            assert r == len(want) and buf.raw[:r] == want, (len(data), level)

@@ -1589,6 +1589,10 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
     {   u64 const ws0 = ((u64)1 << P.wlog) < srcSize ? ((u64)1 << P.wlog) : srcSize;
         blockSize = ws0 < ZSA_BLOCKSIZE_MAX ? (u32)ws0 : ZSA_BLOCKSIZE_MAX;
     }
+    // Without a dictionary the match table is touched by the wave parser only, which then keeps a fingerprint of the 4
+    // bytes at each position in the cell bits the position does not need (zsa_parse.h); indices run up to srcSize + 2.
+    u32 fpPosBits = 0;
+    if (!cd && P.strat == 1) { u32 const bits = 32u - (u32)__builtin_clz(srcSize + 2u); if (bits <= 26) fpPosBits = bits; }
     int const literalsDisabled = (P.strat == 1) && (P.tlen > 0);   // zstd_compress_internal.h:605-618
     u32 const maxDist = 1u << P.wlog;
     u32 remaining = srcSize;
@@ -1639,7 +1643,7 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
                     nbSeq = wv_shfl(nbSeq, 0); lastLL = wv_shfl(lastLL, 0);
                     rep[0] = wv_shfl(rep[0], 0); rep[1] = wv_shfl(rep[1], 0);
                 } else {
-                    nbSeq = zsa_parse_fast_wave(S, hashTable, S->ring, S->seqStage, S->tags, P, Wn.base, Wn.dictLimit, ip, blockSize, rep, W.seq, &lastLL, lane);
+                    nbSeq = zsa_parse_fast_wave(S, hashTable, S->ring, S->seqStage, S->tags, P, Wn.base, Wn.dictLimit, ip, blockSize, rep, W.seq, &lastLL, fpPosBits, lane);
                 }
                 wv_sync();
                 if (lane == 0) {

@@ -164,9 +164,23 @@ template <int MLS> ZSA_DEV u32 zsa_hashT(u64 v, u32 hlog)
 // index 2).  Returns the number of sequences appended to seqOut; rep[] and *lastLL are updated.  All values are wave-uniform.
 template <int MLS>
 ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* seqStage, u8* tags, const ZsaEncParams& P, const u8* base, u32 dictLimit,
-                                 const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL, int lane)
+                                 const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL, u32 posBits, int lane)
 {
     u32 const hlog = P.hlog;
+    // Table cells.  posBits == 0: a cell is the position, as in the reference.  posBits > 0 (frames without a dictionary,
+    // whose table only this parser touches): the low posBits bits are the position and the bits above them a fingerprint
+    // of the 4 bytes at that position.  A probe whose fingerprint differs from the current 4 bytes cannot match, so only
+    // the event that wins the window ever reads its candidate's bytes -- and that read is the first round of the match
+    // extension, which then starts at byte 0 and doubles as the 4-byte check the reference makes (a fingerprint collision
+    // shows up as a common prefix shorter than 4 and the next event of the window is taken instead).
+    bool const useFp = posBits != 0;
+    u32 const posMask = useFp ? ((1u << posBits) - 1u) : 0xFFFFFFFFu;
+#ifdef ZSA_FP_TEST_BITS   // tests: a few fingerprint bits only, so that collisions are common
+#define ZSA_FPV(x) ((((u32)(x) * 2246822519U) >> posBits) & ((1u << ZSA_FP_TEST_BITS) - 1u))
+#else
+#define ZSA_FPV(x) (((u32)(x) * 2246822519U) >> posBits)
+#endif
+#define ZSA_CELL(p, x) (useFp ? ((ZSA_FPV(x) << posBits) | (p)) : (p))
     u32 const stepSize = (P.tlen > 1) ? (P.tlen + 1) : 2;      // zstd_fast.c:153, :429
     u32 const istart = (u32)(src - base), iend = istart + srcSize, ilimit = iend - 8;   // indices
     u32 const maxDistance = 1u << P.wlog;
@@ -205,8 +219,9 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
             while (chkRep2 && ip0 <= ilimit && zsa_ring32(R, ip0 - 2) == RD32(ip0 - rep2)) {
                 u32 const rLength = zsa_count_wave(R, ip0 + 4 - 2, ip0 + 4 - rep2 - 2, iend - 2, lane) + 4;
                 { u32 const t = rep2; rep2 = rep1; rep1 = t; }
-                {   u32 const hh = zsa_hashT<MLS>(zsa_ring64(R, ip0 - 2), hlog);
-                    if (lane == 0) T[hh] = ip0;
+                {   u64 const wd = zsa_ring64(R, ip0 - 2);
+                    u32 const hh = zsa_hashT<MLS>(wd, hlog);
+                    if (lane == 0) T[hh] = ZSA_CELL(ip0, wd);
                     wv_lds_fence();
                 }
                 ip0 += rLength;
@@ -253,26 +268,38 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
             else if (valid) v = r2lane ? zsa_ring64(R, pos - 2) : RD64(pos);
             havePre = false;
             u32 h = 0, old = 0;
+            u32 const myFp = useFp ? ZSA_FPV(v) : 0;
             if (valid && hashLane) { h = zsa_hashT<MLS>(v, hlog); old = T[h]; tags[h & (ZSA_NTAGS - 1)] = (u8)lane; }
+            // the repcode-type events (role 0, lane 63) compare real bytes; their read does not depend on the table and
+            // shares the gather's round trip
+            bool repOK = false;
+            {   bool const rl = valid && (r2lane || (role == 0 && rep1 > 0));
+                u32 const ro = (r2lane ? pos - rep2 : pos - rep1) - 2;
+                u32 rv = zsa_ring32(R, ro);                                  // masked ring address, always legal
+                if (rl && !(ro >= R.lo && ro + 4 <= R.hi)) rv = wv_ldg32_now(R.src + ro);
+                repOK = rl && rv == (u32)v;
+            }
             wv_lds_fence();
             u32 const back = (valid && hashLane) ? tags[h & (ZSA_NTAGS - 1)] : (u32)lane;
             bool const shared = wv_ballot(back != (u32)lane) != 0;
             u64 const vm = wv_ballot(valid && hashLane);
-            u32 cmpIdx = r2lane ? pos - rep2 : (role == 0 ? pos - rep1 : old);
+            u32 cmpIdx = old & posMask, cmpFp = useFp ? old >> posBits : 0;
             if (shared) {   // nearest earlier position of this window in the same cell
                 for (u64 m = vm; m; m &= m - 1) {   // ascending: the last hit is the nearest earlier lane
                     int const s = __builtin_ctzll(m);
-                    u32 const hs = wv_readlane(h, s), qs = wv_readlane(pos, s);
-                    if (hashLane && s < lane && hs == h) cmpIdx = qs;
+                    u32 const hs = wv_readlane(h, s), qs = wv_readlane(pos, s), fs = wv_readlane(myFp, s);
+                    if (hashLane && s < lane && hs == h) { cmpIdx = qs; cmpFp = fs; }
                 }
             }
-            bool const eligible = valid && (r2lane ? true : (role == 0 ? rep1 > 0 : cmpIdx >= prefixStartIndex));
-            bool ok = false;
-            {   // ring read by every lane (masked address, always legal); only candidates older than the ring go to L2
-                u32 const co = cmpIdx - 2;
-                u32 cv = zsa_ring32(R, co);
-                if (eligible && !(co >= R.lo && co + 4 <= R.hi)) cv = wv_ldg32_now(R.src + co);
-                ok = eligible && cv == (u32)v;
+            bool ok = repOK;
+            {   bool const eligible = valid && hashLane && cmpIdx >= prefixStartIndex;
+                if (useFp) ok |= eligible && cmpFp == myFp;
+                else {   // plain cells: compare the candidate's bytes (ring, or L2 for candidates older than the ring)
+                    u32 const co = cmpIdx - 2;
+                    u32 cv = zsa_ring32(R, co);
+                    if (eligible && !(co >= R.lo && co + 4 <= R.hi)) cv = wv_ldg32_now(R.src + co);
+                    ok |= eligible && cv == (u32)v;
+                }
             }
             u64 const found = wv_ballot(ok);
             ZSA_PPROF(S, lane, 8);
@@ -280,8 +307,9 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
             if (found >> 63) {   // immediate repcode: nothing of the speculative window happened
                 u32 const rLength = zsa_count_wave(R, ip0 + 4 - 2, ip0 + 4 - rep2 - 2, iend - 2, lane) + 4;
                 { u32 const t = rep2; rep2 = rep1; rep1 = t; }
-                {   u32 const hh = zsa_hashT<MLS>(wv_readlane((u32)v, 63) | ((u64)wv_readlane((u32)(v >> 32), 63) << 32), hlog);
-                    if (lane == 0) T[hh] = ip0;
+                {   u32 const v63 = wv_readlane((u32)v, 63);
+                    u32 const hh = zsa_hashT<MLS>(v63 | ((u64)wv_readlane((u32)(v >> 32), 63) << 32), hlog);
+                    if (lane == 0) T[hh] = ZSA_CELL(ip0, v63);
                     wv_lds_fence();
                 }
                 ip0 += rLength;
@@ -299,7 +327,20 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
             }
             chkRep2 = false;
 
-            if (!found) {
+            // ---- the event the reference stops at: the first one in lane order that is real
+            int w = -1;
+            u32 vFwd = 0, vBwd = 0;
+            for (u64 cand = found; cand; cand &= cand - 1) {
+                int const c = __builtin_ctzll(cand);
+                u32 const cPair = (u32)c / 3u, cRole = (u32)c - 3u * cPair;
+                if (cRole == 0 || !useFp) { w = c; break; }                 // compared byte for byte already
+                u32 const cur = (fast ? ip0 + 2 * cPair : wv_readlane(myP, c)) + (cRole == 2);
+                u32 const m = wv_readlane(cmpIdx, c);
+                u32 const mb = (cur - anchor) < (m - prefixStartIndex) ? (cur - anchor) : (m - prefixStartIndex);
+                zsa_extend_wave(R, cur - 2, m - 2, iend - 2, cur - 2, m - 2, mb, &vFwd, &vBwd, lane);
+                if (vFwd >= 4) { w = c; break; }                            // else: fingerprint collision, not an event
+            }
+            if (w < 0) {
                 // all positions of the window enter the table; per cell the last one in window order
                 bool dead = false;
                 if (shared) {
@@ -309,14 +350,12 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
                         if (s > lane && hs == h) dead = true;
                     }
                 }
-                if (valid && hashLane && !dead) T[h] = pos;
+                if (valid && hashLane && !dead) T[h] = ZSA_CELL(pos, v);
                 wv_lds_fence();
                 if (nv < ZSA_NP || !(endP + endS + 1 < ilimit)) { blockDone = true; break; }
                 ip0 = endP; sNext = endS; step = endC; nextStep = endNext;
                 continue;
             }
-            // ---- the event the reference stops at
-            int const w = __builtin_ctzll(found);
             u32 const wPair = (u32)w / 3u, wRole = (u32)w - 3u * wPair;
             u32 wP, wS, wC;
             if (fast) { wP = ip0 + 2 * wPair; wS = 2; wC = 2; }
@@ -337,10 +376,10 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
                         if (s > lane && hs == h) dead = true;
                     }
                 }
-                if (keep && !dead) T[h] = pos;
+                if (keep && !dead) T[h] = ZSA_CELL(pos, v);
             }
             wv_lds_fence();
-            if (extra && !xInWin) { u32 const hx = zsa_hashT<MLS>(RD64(xP), hlog); if (lane == 0) T[hx] = xP; wv_lds_fence(); }
+            if (extra && !xInWin) { u64 const vx = RD64(xP); u32 const hx = zsa_hashT<MLS>(vx, hlog); if (lane == 0) T[hx] = ZSA_CELL(xP, vx); wv_lds_fence(); }
 
             ZSA_PPROF(S, lane, 9);
             u32 current0, match0, mLength, offcode, maxBack;
@@ -359,7 +398,11 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
                 offcode = rep1 + 3;
                 maxBack = (ip0 - anchor) < (match0 - prefixStartIndex) ? (ip0 - anchor) : (match0 - prefixStartIndex);
             }
-            {   u32 fwd, bwd;
+            if (wRole != 0 && useFp) {   // extended while it was verified
+                ip0 -= vBwd; match0 -= vBwd;
+                mLength = vBwd + vFwd;
+            } else {
+                u32 fwd, bwd;
                 zsa_extend_wave(R, ip0 + 4 - 2, match0 + 4 - 2, iend - 2, ip0 - 2, match0 - 2, maxBack, &fwd, &bwd, lane);
                 ip0 -= bwd; match0 -= bwd;
                 mLength = 4 + bwd + fwd;
@@ -378,12 +421,12 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
                 {   // :307-309, in this order
                     u32 const pA = current0 + 2, pB = ip0 - 2;
                     u32 const pp = lane == 0 ? pA : pB;
-                    u32 hh;
-                    if (pA - 2 >= R.lo && ip0 + 4 <= R.hi) hh = zsa_hashT<MLS>(zsa_ring64(R, pp - 2), hlog);   // uniform
-                    else { hh = 0; if (lane < 2) hh = zsa_hashT<MLS>(RD64(pp), hlog); }
+                    u32 hh; u64 wd = 0;
+                    if (pA - 2 >= R.lo && ip0 + 4 <= R.hi) { wd = zsa_ring64(R, pp - 2); hh = zsa_hashT<MLS>(wd, hlog); }   // uniform
+                    else { hh = 0; if (lane < 2) { wd = RD64(pp); hh = zsa_hashT<MLS>(wd, hlog); } }
                     // pA then pB: when both fall into one cell only the later one is stored
                     bool const sameCell = wv_readlane(hh, 0) == wv_readlane(hh, 1);
-                    if (lane < 2 && !(lane == 0 && sameCell)) T[hh] = pp;
+                    if (lane < 2 && !(lane == 0 && sameCell)) T[hh] = ZSA_CELL(pp, wd);
                     wv_lds_fence();
                 }
                 chkRep2 = rep2 > 0;   // :311-324 immediate repcode: evaluated with the next window
@@ -395,6 +438,8 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
 #undef RD32
 #undef RD64
 #undef RD8
+#undef ZSA_FPV
+#undef ZSA_CELL
     {   u32 const n = nbSeq & 63;
         wv_lds_fence();
         if ((u32)lane < n) seqOut[nbSeq - n + (u32)lane] = seqStage[lane];
@@ -409,12 +454,12 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
 }
 
 ZSA_DEV u32 zsa_parse_fast_wave(ZsaEncShared* S, u32* T, u32* ringWords, u64* seqStage, u8* tags, const ZsaEncParams& P, const u8* base, u32 dictLimit,
-                                const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL, int lane)
+                                const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL, u32 posBits, int lane)
 {
     switch (P.mml) {
-    case 5:  return zsa_parse_fast_waveT<5>(S, T, ringWords, seqStage, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, lane);
-    case 6:  return zsa_parse_fast_waveT<6>(S, T, ringWords, seqStage, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, lane);
-    case 7:  return zsa_parse_fast_waveT<7>(S, T, ringWords, seqStage, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, lane);
-    default: return zsa_parse_fast_waveT<4>(S, T, ringWords, seqStage, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, lane);
+    case 5:  return zsa_parse_fast_waveT<5>(S, T, ringWords, seqStage, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
+    case 6:  return zsa_parse_fast_waveT<6>(S, T, ringWords, seqStage, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
+    case 7:  return zsa_parse_fast_waveT<7>(S, T, ringWords, seqStage, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
+    default: return zsa_parse_fast_waveT<4>(S, T, ringWords, seqStage, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
     }
 }
