@@ -73,6 +73,7 @@ ZSA_DEV unsigned wv_alignbyte(unsigned hi, unsigned lo, unsigned sh) { return (u
 ZSA_DEV unsigned wv_ldg8(const unsigned char* p) { return *p; }
 ZSA_DEV unsigned wv_ldg32(const unsigned char* p) { unsigned v; memcpy(&v, p, 4); return v; }
 ZSA_DEV unsigned long long wv_ldg64(const unsigned char* p) { unsigned long long v; memcpy(&v, p, 8); return v; }
+ZSA_DEV unsigned wv_vzero() { return 0; }
 ZSA_DEV unsigned wv_ldg_cell(const unsigned* p) { return *p; }
 ZSA_DEV void wv_stg_cell(unsigned* p, unsigned v) { *p = v; }
 ZSA_DEV unsigned wv_ldg8_now(const unsigned char* p) { return wv_ldg8(p); }

@@ -32,6 +32,11 @@ struct __attribute__((packed)) WvPk64 { unsigned long long v; };
 ZSA_DEV unsigned wv_ldg8(const unsigned char* p) { return *(const __attribute__((address_space(1))) unsigned char*)p; }
 ZSA_DEV unsigned wv_ldg32(const unsigned char* p) { return ((const __attribute__((address_space(1))) WvPk32*)p)->v; }
 ZSA_DEV unsigned long long wv_ldg64(const unsigned char* p) { return ((const __attribute__((address_space(1))) WvPk64*)p)->v; }
+// A zero the compiler must treat as a per-lane (vector) value.  Serial sections run by one lane derive all their state from
+// uniform inputs, so the compiler scalarises them -- and a scalarised chain has to pull every loaded value into SGPRs
+// (v_readfirstlane) right behind its load, i.e. wait for it at once.  Seeding such a section's position with this zero
+// keeps its state in VGPRs, where loads can stay in flight until their first real use.
+ZSA_DEV unsigned wv_vzero() { unsigned z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); return z; }
 // aligned table cells in global memory
 ZSA_DEV unsigned wv_ldg_cell(const unsigned* p) { return *(const __attribute__((address_space(1))) unsigned*)p; }
 ZSA_DEV void wv_stg_cell(unsigned* p, unsigned v) { *(__attribute__((address_space(1))) unsigned*)p = v; }
