@@ -65,8 +65,9 @@ size_t zsa_decompress_batch(const void* const* src, const size_t* srcSize, void*
 /* ---------------------------------------------------------------------------------------------------------
  * 3. Batch entry points, device memory -- inputs and outputs already resident in HBM (what bench.py times).
  *    A zsa_batch owns everything a launch needs (frame table, result words, per-workgroup scratch), so
- *    zsa_*_enqueue allocate nothing and only put work on `stream` (a hipStream_t passed as void*; NULL = the
- *    default stream).  All device pointers must belong to the current HIP device.
+ *    zsa_*_enqueue only put work on `stream` (a hipStream_t passed as void*; NULL = the default stream) and allocate
+ *    nothing -- except the first zsa_compress_enqueue on a batch, which allocates that batch's compression workspace
+ *    once (2.6 MiB per resident workgroup).  All device pointers must belong to the current HIP device.
  * ------------------------------------------------------------------------------------------------------- */
 typedef struct zsa_batch_s zsa_batch;
 zsa_batch* zsa_batch_create(size_t maxFrames);

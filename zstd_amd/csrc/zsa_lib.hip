@@ -112,7 +112,9 @@ struct zsa_batch_s {
     ZsaFrameDesc* d_frames;
     u64* d_results; u64* h_results;   // h_results pinned
     u32* d_counter;
-    u8*  d_scratch; size_t scratchBytes;
+    u8*  d_scratch; size_t scratchBytes;          // decode workspace (literal buffer + parked tables), per resident workgroup
+    u8*  d_encScratch; size_t encScratchBytes;    // compression workspace (sequences, literals, staging, match tables): first compress
+    size_t wgs;
     int  numCU;
     u64  maxSrcSize;
     unsigned lastWG, lastLDS;
@@ -219,6 +221,7 @@ extern "C" void zsa_batch_free(zsa_batch* b)
     if (b->d_results) (void)hipFree(b->d_results);
     if (b->d_counter) (void)hipFree(b->d_counter);
     if (b->d_scratch) (void)hipFree(b->d_scratch);
+    if (b->d_encScratch) (void)hipFree(b->d_encScratch);
     if (b->d_prof) (void)hipFree(b->d_prof);
     free(b);
 }
@@ -238,7 +241,9 @@ extern "C" zsa_batch* zsa_batch_create(size_t maxFrames)
     b->numCU = prop.multiProcessorCount;
     size_t const maxWG = (size_t)b->numCU * ZSA_MAX_WG_PER_CU;
     size_t const wgs = maxFrames < maxWG ? maxFrames : maxWG;
-    b->scratchBytes = wgs * (ZSA_ENC_SCRATCH_BYTES > ZSA_DEC_SCRATCH_BYTES ? ZSA_ENC_SCRATCH_BYTES : ZSA_DEC_SCRATCH_BYTES);
+    b->wgs = wgs;
+    b->scratchBytes = wgs * ZSA_DEC_SCRATCH_BYTES;
+    b->encScratchBytes = wgs * ZSA_ENC_SCRATCH_BYTES;   // 2.6 MiB per resident workgroup: allocated by the first compress on this batch
     bool ok = hipHostMalloc((void**)&b->h_frames, maxFrames * sizeof(ZsaFrameDesc), hipHostMallocDefault) == hipSuccess
            && hipHostMalloc((void**)&b->h_results, maxFrames * sizeof(u64), hipHostMallocDefault) == hipSuccess
            && hipMalloc((void**)&b->d_frames, maxFrames * sizeof(ZsaFrameDesc)) == hipSuccess
@@ -299,6 +304,14 @@ extern "C" size_t zsa_compress_enqueue(zsa_batch* b, int level, const zsa_CDict*
 {
     if (!b) return kErrGeneric;
     if (b->nFrames == 0) return 0;
+    if (!b->d_encScratch) {   // once per batch; every later enqueue allocates nothing
+        if (hipMalloc((void**)&b->d_encScratch, b->encScratchBytes) != hipSuccess) {
+            (void)hipGetLastError();
+            fprintf(stderr, "libzstd_amd: device allocation of the compression workspace failed (%zu bytes)\n", b->encScratchBytes);
+            b->d_encScratch = NULL;
+            return (size_t)ZSA_ERR(ZSA_memory_allocation);
+        }
+    }
     size_t const dynLds = 0;
     size_t const ldsPerWG = sizeof(ZsaEncShared) + 64;
     static std::once_flag once;
@@ -306,7 +319,7 @@ extern "C" size_t zsa_compress_enqueue(zsa_batch* b, int level, const zsa_CDict*
     unsigned const grid = zsa_grid(b, ldsPerWG);
     HIPCHK(hipMemsetAsync(b->d_counter, 0, 256, (hipStream_t)stream));
     hipLaunchKernelGGL(zsa_k_compress, dim3(grid), dim3(64), dynLds, (hipStream_t)stream,
-                       b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter, b->d_scratch, level,
+                       b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter, b->d_encScratch, level,
                        cdict ? (const ZsaCDictDev*)cdict->d_cd : (const ZsaCDictDev*)nullptr, b->profOn ? b->d_prof : (u64*)nullptr);
     HIPCHK(hipGetLastError());
     b->lastWG = grid; b->lastLDS = (unsigned)ldsPerWG;
@@ -360,8 +373,15 @@ static size_t zsa_stage_reserve(ZsaStage& st, size_t inBytes, size_t outBytes, s
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { fprintf(stderr, "libzstd_amd: no usable HIP device -- this library has no CPU path\n"); return kErrGeneric; }
-    if (st.device != dev) {   // first use on this thread/device
-        if (st.stream == nullptr) HIPCHK(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
+    if (st.device != dev) {   // first use on this thread, or the thread moved to another device: staging is per device
+        if (st.device != -1) {
+            if (st.h_in) { (void)hipHostFree(st.h_in); (void)hipFree(st.d_in); }
+            if (st.h_out) { (void)hipHostFree(st.h_out); (void)hipFree(st.d_out); }
+            if (st.batch) zsa_batch_free(st.batch);
+            if (st.stream) (void)hipStreamDestroy(st.stream);
+            st.h_in = st.h_out = st.d_in = st.d_out = nullptr; st.inCap = st.outCap = 0; st.batch = nullptr; st.stream = nullptr;
+        }
+        HIPCHK(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
         st.device = dev;
     }
     if (inBytes > st.inCap) {
