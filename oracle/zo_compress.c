@@ -6,13 +6,26 @@
 #include "zstd_oracle.h"
 
 /* ------------------------------------------------------------------ parameters */
-/* clevels.h:26-131: rows {base for negative levels, 1, 2, 3, 4} of the four size classes.  Levels whose strategy is
- * neither ZSTD_fast(1) nor ZSTD_dfast(2) are outside this oracle's scope and reported as unsupported (strat 0 here). */
-static const zo_cparams zo_levelTable[4][5] = {
-    { {19,12,13,1,6,1,1}, {19,13,14,1,7,0,1}, {20,15,16,1,6,0,1}, {21,16,17,1,5,0,2}, {21,18,18,1,5,0,2} },   /* > 256 KB */
-    { {18,12,13,1,5,1,1}, {18,13,14,1,6,0,1}, {18,14,14,1,5,0,2}, {18,16,16,1,4,0,2}, {18,16,17,3,5,2,0} },   /* <= 256 KB */
-    { {17,12,12,1,5,1,1}, {17,12,13,1,6,0,1}, {17,13,15,1,5,0,1}, {17,15,16,2,5,0,2}, {17,17,17,2,4,0,2} },   /* <= 128 KB */
-    { {14,12,13,1,5,1,1}, {14,14,15,1,5,0,1}, {14,14,15,1,4,0,1}, {14,14,15,2,4,0,2}, {14,14,14,4,4,2,0} },   /* <= 16 KB */
+/* clevels.h:26-131: rows {base for negative levels, 1 .. 12} of the four size classes.  Strategies: 1 fast, 2 dfast,
+ * 3 greedy, 4 lazy, 5 lazy2, 6 btlazy2 / 7 btopt (outside this oracle's scope, like the levels above 12: callers reject them). */
+#define ZO_MAX_LEVEL 12
+static const zo_cparams zo_levelTable[4][ZO_MAX_LEVEL + 1] = {
+    {   /* > 256 KB */
+        {19,12,13,1,6,1,1}, {19,13,14,1,7,0,1}, {20,15,16,1,6,0,1}, {21,16,17,1,5,0,2}, {21,18,18,1,5,0,2},
+        {21,18,19,3,5,2,3}, {21,18,19,3,5,4,4}, {21,19,20,4,5,8,4}, {21,19,20,4,5,16,5}, {22,20,21,4,5,16,5},
+        {22,21,22,5,5,16,5}, {22,21,22,6,5,16,5}, {22,22,23,6,5,32,5} },
+    {   /* <= 256 KB */
+        {18,12,13,1,5,1,1}, {18,13,14,1,6,0,1}, {18,14,14,1,5,0,2}, {18,16,16,1,4,0,2}, {18,16,17,3,5,2,3},
+        {18,17,18,5,5,2,3}, {18,18,19,3,5,4,4}, {18,18,19,4,4,4,4}, {18,18,19,4,4,8,5}, {18,18,19,5,4,8,5},
+        {18,18,19,6,4,8,5}, {18,18,19,5,4,12,6}, {18,19,19,7,4,12,6} },
+    {   /* <= 128 KB */
+        {17,12,12,1,5,1,1}, {17,12,13,1,6,0,1}, {17,13,15,1,5,0,1}, {17,15,16,2,5,0,2}, {17,17,17,2,4,0,2},
+        {17,16,17,3,4,2,3}, {17,16,17,3,4,4,4}, {17,16,17,3,4,8,5}, {17,16,17,4,4,8,5}, {17,16,17,5,4,8,5},
+        {17,16,17,6,4,8,5}, {17,17,17,5,4,8,6}, {17,18,17,7,4,12,6} },
+    {   /* <= 16 KB */
+        {14,12,13,1,5,1,1}, {14,14,15,1,5,0,1}, {14,14,15,1,4,0,1}, {14,14,15,2,4,0,2}, {14,14,14,4,4,2,3},
+        {14,14,14,3,4,4,4}, {14,14,14,4,4,8,5}, {14,14,14,6,4,8,5}, {14,14,14,8,4,8,5}, {14,15,14,5,4,8,6},
+        {14,15,14,9,4,8,6}, {14,15,14,3,4,12,7}, {14,15,14,4,3,24,7} },
 };
 
 /* zstd_compress.c:1427-1451 ZSTD_dictAndWindowLog */
@@ -58,7 +71,7 @@ static zo_cparams zo_adjustCParams(zo_cparams cp, u64 srcSize, size_t dictSize, 
     return cp;
 }
 /* zstd_compress.c:6935-6983 ZSTD_getCParamRowSize + ZSTD_getCParams_internal.
- * Returns 0 and fills *out, or 1 when the level is outside the table kept here (> 4, or a greedy row). */
+ * Returns 0 and fills *out, or 1 when the level is outside the table kept here (> 12, or a btlazy2 row). */
 int zo_getCParams(zo_cparams* out, int level, u64 srcSizeHint, size_t dictSize, int mode)
 {
     u64 rSize;
@@ -72,10 +85,10 @@ int zo_getCParams(zo_cparams* out, int level, u64 srcSizeHint, size_t dictSize, 
     tableID = (rSize <= 256 * 1024) + (rSize <= 128 * 1024) + (rSize <= 16 * 1024);
     if (level == 0) row = 3;          /* ZSTD_CLEVEL_DEFAULT */
     else if (level < 0) row = 0;
-    else if (level > 4) return 1;
+    else if (level > ZO_MAX_LEVEL) return 1;
     else row = level;
     {   zo_cparams cp = zo_levelTable[tableID][row];
-        if (cp.strat == 0) return 1;
+        if (cp.strat > 5) return 1;
         if (level < 0) {
             int const minLevel = -(1 << 17);   /* ZSTD_minCLevel() == -ZSTD_TARGETLENGTH_MAX */
             int const clamped = level < minLevel ? minLevel : level;
@@ -96,6 +109,13 @@ typedef struct {
     u32* chainTable;       /* ZSTD_dfast: the short-hash table (zstd_double_fast.c:106) */
     zo_cparams cp;
     const zo_cdict* dms;   /* attached dictionary (dictMatchState), or NULL */
+    /* greedy / lazy / lazy2 (zo_lazy.inc) */
+    u32 nextToUpdate;      /* first index not yet entered into the tables */
+    u32 lazySkipping;
+    int useRow;            /* row-hash match finder (windowLog > 14) instead of the hash chain */
+    u8* tagTable;          /* row finder: one tag byte per hash-table entry, byte 0 of a row is its head */
+    u32 rowHashLog;
+    u64 hashSalt;
 } zo_matchstate;
 
 /* zstd_compress_internal.h:809-846 ZSTD_hashPtr for mls 4..8 */
@@ -276,6 +296,7 @@ static size_t zo_fast_noDict(zo_matchstate* ms, zo_seqstore* ss, u32 rep[3], con
 }
 
 #include "zo_dfast.inc"
+#include "zo_lazy.inc"
 
 /* ------------------------------------------------------------------ the level-1 parse, attached dictionary */
 /* zstd_fast.c:459-656 ZSTD_compressBlock_fast_dictMatchState_generic (hasStep == 0) */
@@ -640,9 +661,18 @@ static size_t zo_compressFrame(u8* dst, size_t dstCapacity, const u8* src, size_
     }
     ms.cp = cp;
     ms.hashTable = (u32*)calloc((size_t)1 << cp.hlog, sizeof(u32));
-    if (cp.strat == 2) {   /* zstd_compress.c:1941-1943: the chain table exists for every strategy but ZSTD_fast */
+    /* zstd_compress.c:236-252 ZSTD_resolveRowMatchFinderMode (SIMD build) and :1977-1996 */
+    ms.useRow = (cp.strat >= 3 && cp.strat <= 5) && (cp.wlog > 14);
+    if (cp.strat >= 2 && !ms.useRow) {   /* :262-270: a chain table for every strategy but ZSTD_fast and the row finder */
         ms.chainTable = (u32*)calloc((size_t)1 << cp.clog, sizeof(u32));
         if (!ms.chainTable) { result = ZO_ERR(memory_allocation); goto done; }
+    }
+    if (ms.useRow) {
+        u32 const rowLog = cp.slog < 4 ? 4 : (cp.slog > 6 ? 6 : cp.slog);
+        ms.tagTable = (u8*)calloc((size_t)1 << cp.hlog, 1);
+        if (!ms.tagTable) { result = ZO_ERR(memory_allocation); goto done; }
+        ms.rowHashLog = cp.hlog - rowLog;
+        ms.hashSalt = zo_freshHashSalt();
     }
     ss.maxNbSeq = (u32)(blockSize / ((cp.mml == 3) ? 3 : 4)) + 1;
     ss.seq = (zo_seqdef*)malloc((ss.maxNbSeq + 1) * sizeof(zo_seqdef));
@@ -653,6 +683,7 @@ static size_t zo_compressFrame(u8* dst, size_t dstCapacity, const u8* src, size_
 
     /* zstd_compress_internal.h:1232-1285 window_init + first window_update: first byte has index 2 */
     ms.base = src - 2; ms.dictBase = src - 2; ms.dictLimit = 2; ms.lowLimit = 2; ms.loadedDictEnd = 0; ms.dms = NULL;
+    ms.nextToUpdate = 2;   /* zstd_compress.c:4596-4599 */
     if (cdict != NULL) {
         u32 const cdictEnd = cdict->endIndex;          /* window.nextSrc - window.base of the dictionary's match state */
         u32 const cdictLen = cdictEnd - 2;
@@ -713,6 +744,7 @@ static size_t zo_compressFrame(u8* dst, size_t dstCapacity, const u8* src, size_
                 ms.loadedDictEnd = 0; ms.dms = NULL;
             }
         }
+        if (ms.nextToUpdate < ms.lowLimit) ms.nextToUpdate = ms.lowLimit;   /* zstd_compress.c:4427 */
 
         /* zstd_compress.c:3147-3306 ZSTD_buildSeqStore */
         if (blockSize < 1 + 1 + 3 + 1 + 1) {   /* MIN_CBLOCK_SIZE + blockHeader + 1 + 1 == 7 */
@@ -722,7 +754,15 @@ static size_t zo_compressFrame(u8* dst, size_t dstCapacity, const u8* src, size_
             ss.nbSeq = 0; ss.litSize = 0; ss.longLengthType = 0;
             bsNext->rep[0] = bsPrev->rep[0]; bsNext->rep[1] = bsPrev->rep[1]; bsNext->rep[2] = bsPrev->rep[2];
             /* zstd_compress_internal.h:971-978 ZSTD_matchState_dictMode */
-            if (cp.strat == 2)              lastLL = zo_dfast_noDict(&ms, &ss, bsNext->rep, ip, blockSize);   /* no dictionary at this strategy here */
+            /* :3174-3181 limited update after a very long match */
+            {   u32 const curr = (u32)(ip - ms.base);
+                if (curr > ms.nextToUpdate + 384) {
+                    u32 const gap = curr - ms.nextToUpdate - 384;
+                    ms.nextToUpdate = curr - (gap < 192 ? gap : 192);
+                }
+            }
+            if (cp.strat >= 3)              lastLL = zo_lazy_noDict(&ms, &ss, bsNext->rep, ip, blockSize, cp.strat - 3);   /* no dictionary at these strategies here */
+            else if (cp.strat == 2)         lastLL = zo_dfast_noDict(&ms, &ss, bsNext->rep, ip, blockSize);   /* no dictionary at this strategy here */
             else if (ms.lowLimit < ms.dictLimit) lastLL = zo_fast_extDict(&ms, &ss, bsNext->rep, ip, blockSize);
             else if (ms.dms)                lastLL = zo_fast_dictMatchState(&ms, &ss, bsNext->rep, ip, blockSize);
             else                            lastLL = zo_fast_noDict(&ms, &ss, bsNext->rep, ip, blockSize);
@@ -759,7 +799,7 @@ static size_t zo_compressFrame(u8* dst, size_t dstCapacity, const u8* src, size_
     }
     result = (size_t)(op - dst);
 done:
-    free(ms.hashTable); free(ms.chainTable); free(ss.seq); free(ss.lit); free(codeWksp); free(bsPrev); free(bsNext);
+    free(ms.hashTable); free(ms.chainTable); free(ms.tagTable); free(ss.seq); free(ss.lit); free(codeWksp); free(bsPrev); free(bsNext);
     return result;
 }
 
@@ -776,8 +816,8 @@ size_t zo_compress_dump(void* dst, size_t dstCapacity, const void* src, size_t s
 {
     zo_cparams cp;
     static const u8 empty[8] = {0};
-    if (zo_getCParams(&cp, level, (u64)srcSize, 0, zo_cpm_noAttachDict) || (cp.strat != 1 && cp.strat != 2))
-        return ZO_ERR(parameter_unsupported);   /* oracle scope: ZSTD_fast and ZSTD_dfast levels only */
+    if (zo_getCParams(&cp, level, (u64)srcSize, 0, zo_cpm_noAttachDict))
+        return ZO_ERR(parameter_unsupported);   /* oracle scope: the ZSTD_fast .. ZSTD_lazy2 levels */
     if (srcSize > 0xE0000000u) return ZO_ERR(srcSize_wrong);   /* index overflow correction not restated */
     if (src == NULL) src = empty;
     return zo_compressFrame((u8*)dst, dstCapacity, (const u8*)src, srcSize, cp, NULL, zo_dm_none, dump, dumpArg);

@@ -658,10 +658,10 @@ static size_t zo_rleLiterals(u8* dst, const u8* src, size_t srcSize)
 }
 static int zo_allBytesIdentical(const u8* src, size_t n) { size_t p; for (p = 1; p < n; p++) if (src[p] != src[0]) return 0; return 1; }
 
-/* zstd_compress_literals.c:130-236 ZSTD_compressLiterals at strategy ZSTD_fast(=1) */
+/* zstd_compress_literals.c:130-236 ZSTD_compressLiterals (strategies fast .. lazy2: same thresholds, :115-128) */
 static size_t zo_compressLiterals(u8* dst, size_t dstCapacity, const u8* src, size_t srcSize,
                                   const zo_entropy* prev, zo_entropy* next,
-                                  int disableLiteralCompression, int suspectUncompressible)
+                                  int disableLiteralCompression, int suspectUncompressible, int strategy)
 {
     size_t const lhSize = 3 + (srcSize >= 1024) + (srcSize >= 16384);
     u32 singleStream = srcSize < 256;
@@ -675,7 +675,7 @@ static size_t zo_compressLiterals(u8* dst, size_t dstCapacity, const u8* src, si
         if (srcSize < mintc) return zo_noCompressLiterals(dst, src, srcSize);
     }
     {   int repeat = prev->huf_repeat;
-        int const preferRepeat = (srcSize <= 1024);   /* strategy < ZSTD_lazy */
+        int const preferRepeat = (strategy < 4) && (srcSize <= 1024);   /* :166: strategy < ZSTD_lazy */
         if (repeat == zo_rep_valid && lhSize == 3) singleStream = 1;
         cLitSize = zo_huf_compress(dst + lhSize, dstCapacity - lhSize, src, srcSize, !singleStream,
                                    &next->huf, &repeat, preferRepeat, suspectUncompressible);
@@ -733,23 +733,111 @@ static void zo_seqToCodes(const zo_seqstore* ss, u8* llCode, u8* ofCode, u8* mlC
     if (ss->longLengthType == 1) llCode[ss->longLengthPos] = ZO_MaxLL;
     if (ss->longLengthType == 2) mlCode[ss->longLengthPos] = ZO_MaxML;
 }
-/* zstd_compress_sequences.c:157-236 ZSTD_selectEncodingType, the `strategy < ZSTD_lazy` branch (:180-205) */
-static int zo_selectEncodingType(int* repeatMode, u32 mostFrequent, size_t nbSeq, u32 defaultNormLog, int isDefaultAllowed, int strategy)
+/* zstd_compress_sequences.c:22-45 kInverseProbabilityLog256: floor(-log2(x / 256) * 256) for x in [1, 256), 0 for
+ * x == 0 (tests/test_oracle.py re-derives the 255 values from that formula). */
+static const u16 zo_invProbLog256[256] = {
+    0,    2048, 1792, 1642, 1536, 1453, 1386, 1329, 1280, 1236, 1197, 1162, 1130, 1100, 1073, 1047,
+    1024, 1001, 980,  960,  941,  923,  906,  889,  874,  859,  844,  830,  817,  804,  791,  779,
+    768,  756,  745,  734,  724,  714,  704,  694,  685,  676,  667,  658,  650,  642,  633,  626,
+    618,  610,  603,  595,  588,  581,  574,  567,  561,  554,  548,  542,  535,  529,  523,  517,
+    512,  506,  500,  495,  489,  484,  478,  473,  468,  463,  458,  453,  448,  443,  438,  434,
+    429,  424,  420,  415,  411,  407,  402,  398,  394,  390,  386,  382,  377,  373,  370,  366,
+    362,  358,  354,  350,  347,  343,  339,  336,  332,  329,  325,  322,  318,  315,  311,  308,
+    305,  302,  298,  295,  292,  289,  286,  282,  279,  276,  273,  270,  267,  264,  261,  258,
+    256,  253,  250,  247,  244,  241,  239,  236,  233,  230,  228,  225,  222,  220,  217,  215,
+    212,  209,  207,  204,  202,  199,  197,  194,  192,  190,  187,  185,  182,  180,  178,  175,
+    173,  171,  168,  166,  164,  162,  159,  157,  155,  153,  151,  149,  146,  144,  142,  140,
+    138,  136,  134,  132,  130,  128,  126,  123,  121,  119,  117,  115,  114,  112,  110,  108,
+    106,  104,  102,  100,  98,   96,   94,   93,   91,   89,   87,   85,   83,   82,   80,   78,
+    76,   74,   73,   71,   69,   67,   66,   64,   62,   61,   59,   57,   55,   54,   52,   50,
+    49,   47,   46,   44,   42,   41,   39,   37,   36,   34,   33,   31,   30,   28,   26,   25,
+    23,   22,   20,   19,   17,   16,   14,   13,   11,   10,   8,    7,    5,    4,    2,    1,
+};
+#define ZO_COST_ERROR ((size_t)-1)   /* ERROR(GENERIC): larger than any real cost */
+/* zstd_compress_sequences.c:71-79 ZSTD_NCountCost: size of the table description a "compressed" mode would write */
+static size_t zo_NCountCost(const u32* count, u32 max, size_t nbSeq, u32 FSELog)
+{
+    u8 wksp[512];
+    s16 norm[ZO_MaxSeq + 1];
+    u32 const tableLog = zo_fse_optimalTableLog(FSELog, nbSeq, max, 2);
+    { size_t const e = zo_fse_normalizeCount(norm, tableLog, count, nbSeq, max, nbSeq >= 2048); if (zo_isErr(e)) return e; }
+    return zo_fse_writeNCount(wksp, sizeof(wksp), norm, max, tableLog);
+}
+/* :85-99 ZSTD_entropyCost */
+static size_t zo_entropyCost(const u32* count, u32 max, size_t total)
+{
+    u32 cost = 0, s;
+    for (s = 0; s <= max; ++s) {
+        u32 norm = (u32)((256 * count[s]) / total);
+        if (count[s] != 0 && norm == 0) norm = 1;
+        cost += count[s] * zo_invProbLog256[norm];
+    }
+    return cost >> 8;
+}
+/* :105-133 ZSTD_fseBitCost with fse.h:494-509 FSE_bitCost (accuracyLog 8) */
+static size_t zo_fseBitCost(const zo_seq_ctable* ct, const u32* count, u32 max)
+{
+    u32 const kAccuracyLog = 8;
+    u32 const tableLog = ct->tableLog;
+    size_t cost = 0;
+    u32 s;
+    if (ct->maxSV < max) return ZO_COST_ERROR;
+    for (s = 0; s <= max; ++s) {
+        u32 const badCost = (tableLog + 1) << kAccuracyLog;
+        u32 const minNbBits = ct->deltaNbBits[s] >> 16;
+        u32 const threshold = (minNbBits + 1) << 16;
+        u32 const tableSize = 1u << tableLog;
+        u32 const deltaFromThreshold = threshold - (ct->deltaNbBits[s] + tableSize);
+        u32 const normalizedDeltaFromThreshold = (deltaFromThreshold << kAccuracyLog) >> tableLog;
+        u32 const bitCost = ((minNbBits + 1) << kAccuracyLog) - normalizedDeltaFromThreshold;
+        if (count[s] == 0) continue;
+        if (bitCost >= badCost) return ZO_COST_ERROR;
+        cost += (size_t)count[s] * bitCost;
+    }
+    return cost >> kAccuracyLog;
+}
+/* :140-155 ZSTD_crossEntropyCost */
+static size_t zo_crossEntropyCost(const s16* norm, u32 accuracyLog, const u32* count, u32 max)
+{
+    u32 const shift = 8 - accuracyLog;
+    size_t cost = 0;
+    u32 s;
+    for (s = 0; s <= max; ++s) {
+        u32 const normAcc = (norm[s] != -1) ? (u32)norm[s] : 1;
+        u32 const norm256 = normAcc << shift;
+        cost += count[s] * zo_invProbLog256[norm256];
+    }
+    return cost >> 8;
+}
+/* zstd_compress_sequences.c:157-236 ZSTD_selectEncodingType: the threshold rules below ZSTD_lazy (:180-205), the cost
+ * estimates from ZSTD_lazy on (:206-232) */
+static int zo_selectEncodingType(int* repeatMode, const u32* count, u32 max, u32 mostFrequent, size_t nbSeq, u32 FSELog,
+                                 const zo_seq_ctable* prevCTable, const s16* defaultNorm, u32 defaultNormLog,
+                                 int isDefaultAllowed, int strategy)
 {
     if (mostFrequent == nbSeq) {
         *repeatMode = zo_rep_none;
         if (isDefaultAllowed && nbSeq <= 2) return zo_set_basic;
         return zo_set_rle;
     }
-    if (isDefaultAllowed) {
-        size_t const staticFse_nbSeq_max = 1000;
-        size_t const mult = (size_t)(10 - strategy);   /* :185: ZSTD_fast == 1, ZSTD_dfast == 2 */
-        size_t const dynamicFse_nbSeq_min = (((size_t)1 << defaultNormLog) * mult) >> 3;
-        if ((*repeatMode == zo_rep_valid) && (nbSeq < staticFse_nbSeq_max)) return zo_set_repeat;
-        if ((nbSeq < dynamicFse_nbSeq_min) || (mostFrequent < (nbSeq >> (defaultNormLog - 1)))) {
-            *repeatMode = zo_rep_none;
-            return zo_set_basic;
+    if (strategy < 4) {   /* < ZSTD_lazy */
+        if (isDefaultAllowed) {
+            size_t const staticFse_nbSeq_max = 1000;
+            size_t const mult = (size_t)(10 - strategy);   /* :183 */
+            size_t const dynamicFse_nbSeq_min = (((size_t)1 << defaultNormLog) * mult) >> 3;
+            if ((*repeatMode == zo_rep_valid) && (nbSeq < staticFse_nbSeq_max)) return zo_set_repeat;
+            if ((nbSeq < dynamicFse_nbSeq_min) || (mostFrequent < (nbSeq >> (defaultNormLog - 1)))) {
+                *repeatMode = zo_rep_none;
+                return zo_set_basic;
+            }
         }
+    } else {
+        size_t const basicCost = isDefaultAllowed ? zo_crossEntropyCost(defaultNorm, defaultNormLog, count, max) : ZO_COST_ERROR;
+        size_t const repeatCost = *repeatMode != zo_rep_none ? zo_fseBitCost(prevCTable, count, max) : ZO_COST_ERROR;
+        size_t const NCountCost = zo_NCountCost(count, max, nbSeq, FSELog);
+        size_t const compressedCost = (NCountCost << 3) + zo_entropyCost(count, max, nbSeq);
+        if (basicCost <= repeatCost && basicCost <= compressedCost) { *repeatMode = zo_rep_none; return zo_set_basic; }
+        if (repeatCost <= compressedCost) return zo_set_repeat;
     }
     *repeatMode = zo_rep_check;
     return zo_set_compressed;
@@ -822,7 +910,7 @@ static size_t zo_encodeSequences(u8* dst, const zo_seq_ctable* ctML, const u8* m
  * Returns the compressed block body size, 0 for "emit raw", or an error. */
 size_t zo_entropyCompressSeqStore(const zo_seqstore* ss, const zo_entropy* prev, zo_entropy* next,
                                   int literalsDisabled, u8* dst, size_t dstCapacity, size_t srcSize,
-                                  u8* codeWksp /* 3*maxNbSeq bytes */, int strategy /* 1 fast, 2 dfast */)
+                                  u8* codeWksp /* 3*maxNbSeq bytes */, int strategy /* 1 fast .. 5 lazy2 */)
 {
     u8* const ostart = dst;
     u8* const oend = dst + dstCapacity;
@@ -836,7 +924,7 @@ size_t zo_entropyCompressSeqStore(const zo_seqstore* ss, const zo_entropy* prev,
 
     {   size_t const litSize = ss->litSize;
         int const suspect = (nbSeq == 0) || (litSize / nbSeq >= 20);
-        size_t const c = zo_compressLiterals(op, dstCapacity, ss->lit, litSize, prev, next, literalsDisabled, suspect);
+        size_t const c = zo_compressLiterals(op, dstCapacity, ss->lit, litSize, prev, next, literalsDisabled, suspect, strategy);
         if (zo_isErr(c)) return c;
         op += c;
     }
@@ -855,7 +943,8 @@ size_t zo_entropyCompressSeqStore(const zo_seqstore* ss, const zo_entropy* prev,
         {   u32 max = ZO_MaxLL;
             u32 const mostFrequent = zo_hist(count, &max, llCode, nbSeq);
             next->ll_repeat = prev->ll_repeat;
-            LLtype = zo_selectEncodingType(&next->ll_repeat, mostFrequent, nbSeq, ZO_LL_DEFAULTNORMLOG, 1, strategy);
+            LLtype = zo_selectEncodingType(&next->ll_repeat, count, max, mostFrequent, nbSeq, ZO_LLFSELog, &prev->ll,
+                                           zo_LL_defaultNorm, ZO_LL_DEFAULTNORMLOG, 1, strategy);
             {   size_t const cs = zo_buildSeqCTable(op, (size_t)(oend - op), &next->ll, ZO_LLFSELog, LLtype, count, max, llCode, nbSeq,
                                                     zo_LL_defaultNorm, ZO_LL_DEFAULTNORMLOG, ZO_MaxLL, &prev->ll);
                 if (zo_isErr(cs)) return cs;
@@ -867,7 +956,8 @@ size_t zo_entropyCompressSeqStore(const zo_seqstore* ss, const zo_entropy* prev,
             u32 const mostFrequent = zo_hist(count, &max, ofCode, nbSeq);
             int const defaultAllowed = (max <= ZO_DefaultMaxOff);
             next->of_repeat = prev->of_repeat;
-            OFtype = zo_selectEncodingType(&next->of_repeat, mostFrequent, nbSeq, ZO_OF_DEFAULTNORMLOG, defaultAllowed, strategy);
+            OFtype = zo_selectEncodingType(&next->of_repeat, count, max, mostFrequent, nbSeq, ZO_OffFSELog, &prev->of,
+                                           zo_OF_defaultNorm, ZO_OF_DEFAULTNORMLOG, defaultAllowed, strategy);
             {   size_t const cs = zo_buildSeqCTable(op, (size_t)(oend - op), &next->of, ZO_OffFSELog, OFtype, count, max, ofCode, nbSeq,
                                                     zo_OF_defaultNorm, ZO_OF_DEFAULTNORMLOG, ZO_DefaultMaxOff, &prev->of);
                 if (zo_isErr(cs)) return cs;
@@ -878,7 +968,8 @@ size_t zo_entropyCompressSeqStore(const zo_seqstore* ss, const zo_entropy* prev,
         {   u32 max = ZO_MaxML;
             u32 const mostFrequent = zo_hist(count, &max, mlCode, nbSeq);
             next->ml_repeat = prev->ml_repeat;
-            MLtype = zo_selectEncodingType(&next->ml_repeat, mostFrequent, nbSeq, ZO_ML_DEFAULTNORMLOG, 1, strategy);
+            MLtype = zo_selectEncodingType(&next->ml_repeat, count, max, mostFrequent, nbSeq, ZO_MLFSELog, &prev->ml,
+                                           zo_ML_defaultNorm, ZO_ML_DEFAULTNORMLOG, 1, strategy);
             {   size_t const cs = zo_buildSeqCTable(op, (size_t)(oend - op), &next->ml, ZO_MLFSELog, MLtype, count, max, mlCode, nbSeq,
                                                     zo_ML_defaultNorm, ZO_ML_DEFAULTNORMLOG, ZO_MaxML, &prev->ml);
                 if (zo_isErr(cs)) return cs;
