@@ -84,19 +84,20 @@ extern "C" size_t emu_compress(void* dst, size_t cap, const void* src, size_t n,
     return (size_t)A.result;
 }
 
-// parameters resolved from the level as the kernel does (ZSTD_fast and ZSTD_dfast rows)
+// parameters resolved from the level as the kernel does (ZSTD_fast .. ZSTD_lazy2 rows)
 extern "C" size_t emu_compress_level(void* dst, size_t cap, const void* src, size_t n, int level)
 {
     static ZsaEncShared S;
-    static u32* ht = (u32*)malloc((size_t)2 << 20);
+    static u32* ht = (u32*)malloc((size_t)5 << 20);
     static u64* seq = (u64*)malloc(8 * (32768 + 64));
     static u8* lit = (u8*)malloc(ZSA_BLOCKSIZE_MAX + 128);
     static u8* tmp = (u8*)malloc(ZSA_BLOCKSIZE_MAX * 2 + 512);
+    static ZsaFseCT park[3];
     static const u8 empty[16] = {0};
     ZsaCParams cp;
-    if (zsa_resolveCParams(&cp, level, n, 0, zsa_cpm_noAttachDict) || !(cp.strat == 1 || cp.strat == 2)
-        || ((size_t)4 << cp.hlog) + (cp.strat == 2 ? ((size_t)4 << cp.clog) : 0) > ((size_t)2 << 20)) return (size_t)ZSA_ERR(ZSA_parameter_unsupported);
-    EncArgs A = { &S, ht, { cp.wlog, cp.hlog, cp.mml, cp.tlen, cp.clog, cp.strat }, n ? (const u8*)src : empty + 8, n, (u8*)dst, cap, { seq, lit, tmp }, nullptr, 0, 0 };
+    if (zsa_resolveCParams(&cp, level, n, 0, zsa_cpm_noAttachDict)
+        || ((size_t)4 << cp.hlog) + zsa_auxTableBytes(cp.strat, cp.wlog, cp.hlog, cp.clog) > ((size_t)5 << 20)) return (size_t)ZSA_ERR(ZSA_parameter_unsupported);
+    EncArgs A = { &S, ht, { cp.wlog, cp.hlog, cp.mml, cp.tlen, cp.clog, cp.strat, cp.slog }, n ? (const u8*)src : empty + 8, n, (u8*)dst, cap, { seq, lit, tmp, park }, nullptr, 0, 0 };
     emu_run_wave(enc_entry, &A);
     return (size_t)A.result;
 }
@@ -153,7 +154,7 @@ extern "C" size_t emu_compress_cdict(void* dst, size_t cap, const void* src, siz
     const EmuCDict* c = (const EmuCDict*)h;
     ZsaCParams cp; int mode = 0;
     if (zsa_resolveCDictUse(&cp, &mode, c->cd.cp, c->cd.level, c->cd.dictSize, n) || cp.strat != 1 || cp.hlog > 17) return (size_t)ZSA_ERR(ZSA_parameter_unsupported);
-    EncArgs A = { &S, ht, { cp.wlog, cp.hlog, cp.mml, cp.tlen, cp.clog, cp.strat }, n ? (const u8*)src : empty + 8, n, (u8*)dst, cap, { seq, lit, tmp }, &c->cd, mode, 0 };
+    EncArgs A = { &S, ht, { cp.wlog, cp.hlog, cp.mml, cp.tlen, cp.clog, cp.strat, cp.slog }, n ? (const u8*)src : empty + 8, n, (u8*)dst, cap, { seq, lit, tmp, nullptr }, &c->cd, mode, 0 };
     emu_run_wave(enc_entry, &A);
     return (size_t)A.result;
 }

@@ -114,6 +114,31 @@ def test_emulated_dfast_parse_matches_oracle(emu, oracle):
                 assert r == len(want) and buf.raw[:r] == want, (len(d), level)
 
 
+def test_emulated_lazy_parse_matches_oracle(emu, oracle):
+    """zsa_lazy.h (greedy / lazy / lazy2 with the hash-chain and the row-hash match finders: levels 4..12 where clevels.h
+    selects them; level 5 is the reference's default) through the whole frame encoder, cost-based sequence modes and
+    multi-block repeat tables included"""
+    rnd = random.Random(5)
+    cases = [b"", b"abc", b"abcdefg" * 3, corpus.frames("json", 1000, 1, 7)[0], corpus.frames("log", 16384, 1, 5)[0],
+             corpus.frames("log", 20000, 1, 5)[0], corpus.frames("json", 70000, 1, 3)[0], corpus.frames("log", 131072, 1, 4)[0],
+             corpus.frames("log", 300000, 1, 4)[0], bytes(300) + b"xyz" * 500 + bytes(range(256)) * 4,
+             rnd.randbytes(5000) + bytes(3000) + rnd.randbytes(40), bytes(200000),
+             b"".join(rnd.choice([b"alpha ", b"beta ", b"gamma ", b"delta=%d " % rnd.randrange(50)]) for _ in range(60000))]
+    n_checked = 0
+    for d in cases:
+        for level in (5, 6, 7, 4, 9, 12):
+            want = oracle.compress(d, level)
+            cap = zstd_amd.CompressBound(len(d))
+            buf = ctypes.create_string_buffer(cap + 1)
+            r = emu.emu_compress_level(buf, cap, d, len(d), level)
+            if isinstance(want, int):
+                assert r == 2 ** 64 + want, (len(d), level)
+            else:
+                assert r == len(want) and buf.raw[:r] == want, (len(d), level)
+                n_checked += 1
+    assert n_checked >= 50
+
+
 def test_emulated_fingerprint_collisions(oracle):
     """zsa_parse.h keeps a fingerprint of the 4 bytes at each position in the spare bits of a match-table cell and only
     reads a candidate's bytes when it wins its window; with 2-bit fingerprints (test build) one probe in four collides,

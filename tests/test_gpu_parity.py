@@ -62,7 +62,7 @@ def test_reference_go_cases(z, oracle):
     # zstd_test.go:60-88 (Hello World round trip), :119-142 (payload matrix at the levels this engine implements),
     # :216-254 (empty input / output), :325-342 (small payload)
     payloads = [b"", b"\x00", b"Hello World!", b"a" * 3, bytes(range(256)) * 3]
-    for level in (1, -1, -3, 2):
+    for level in (1, -1, -3, 2, 3, 4, 5, 6, 7, 8):
         got = _check_compress(z, oracle, payloads, level)
         assert z.DecompressBatch(got, [max(len(p), 1) for p in payloads]) == payloads
     c = z.CompressLevel(None, b"Hello World!", 1)
@@ -70,8 +70,10 @@ def test_reference_go_cases(z, oracle):
     assert z.Decompress(bytearray(3), c) == b"Hello World!"          # dst too small: reallocated
     with pytest.raises(z.api.ZstdError):
         z.Decompress(None, b"")                                       # ErrEmptySlice, zstd.go:135-137
-    # levels whose strategy is neither ZSTD_fast nor ZSTD_dfast are outside the engine and say so
-    r = z.CompressBatch([b"x" * 100], 5)
+    # zstd.go:90-92: Compress == CompressLevel(DefaultCompression = 5), ZSTD_lazy with the hash chain at this size
+    assert z.Compress(None, b"Hello World!") == oracle.compress(b"Hello World!", 5)
+    # levels whose strategy is ZSTD_btlazy2 or above are outside the engine and say so
+    r = z.CompressBatch([b"x" * 100], 13)
     assert isinstance(r[0], z.ErrorCode) and str(r[0]) == "Unsupported parameter"
 
 
@@ -306,9 +308,48 @@ def test_dfast_levels_match_golden(z, oracle):
         for f, c in zip(ragged, got):
             want = oracle.compress(f, level)
             if isinstance(want, int):
-                assert isinstance(c, z.ErrorCode) and str(c) == "Unsupported parameter"   # level 4 is ZSTD_greedy at <= 16 KB
+                assert isinstance(c, z.ErrorCode) and str(c) == "Unsupported parameter"
             else:
                 assert c == want, (len(f), level)
+
+
+def test_lazy_levels_match_golden(z, oracle):
+    """the levels whose strategy is ZSTD_greedy / ZSTD_lazy / ZSTD_lazy2 -- 5 is the default of the
+    reference's Compress() (zstd.go:23,90-92) -- byte-identical to the reference-generated fixture: hash-chain finder
+    (windowLog <= 14) and row-hash finder, single- and multi-block frames (repeat / cost-selected sequence tables)"""
+    from zstd_amd import corpus
+    g = json.load(open(os.path.join(HERE, "golden", "lazy_frames.json")))
+    by_level = {}
+    for k in g["cases"]:
+        by_level.setdefault(k["level"], []).append(k)
+    for level, items in by_level.items():
+        srcs = [bytes.fromhex(k["src_hex"]) for k in items]
+        got = z.CompressBatch(srcs, level)
+        for k, c in zip(items, got):
+            assert isinstance(c, bytes) and c.hex() == k["c_hex"], (k["name"], level)
+        assert z.DecompressBatch(got, [max(len(s), 1) for s in srcs]) == srcs
+    for t in g["tables"]:
+        frames = corpus.frames(t["kind"], t["frame_size"], t["n"], t["seed"])
+        got = z.CompressBatch(frames, t["level"])
+        for c, (clen, chash, _) in zip(got, t["rows"]):
+            assert isinstance(c, bytes) and len(c) == clen and hashlib.sha256(c).hexdigest()[:32] == chash, (t["kind"], t["frame_size"], t["level"])
+        assert z.DecompressBatch(got, [t["frame_size"]] * t["n"]) == frames
+    # the default-level one-shot entry point, and ragged sizes and shapes against the oracle
+    d = corpus.frames("json", 50000, 1, 21)[0]
+    assert z.Compress(None, d) == oracle.compress(d, 5)
+    rnd = random.Random(6)
+    ragged = [corpus.frames("log", rnd.choice([1, 8, 9, 15, 16, 17, 300, 4000, 16384, 16385, 100000, 131073, 262145]), 1, 30 + i)[0] for i in range(24)]
+    ragged += [bytes(200000), rnd.randbytes(70000), rnd.randbytes(3000) + bytes(150000) + rnd.randbytes(3000), b"ab" * 40000,
+               bytes(rnd.choice(b"abcde") for _ in range(50000))]
+    for level in (5, 6, 8, 12):
+        got = z.CompressBatch(ragged, level)
+        for f, c in zip(ragged, got):
+            want = oracle.compress(f, level)
+            if isinstance(want, int):
+                assert isinstance(c, z.ErrorCode) and str(c) == "Unsupported parameter"   # level 12 is btlazy2 / btopt at <= 256 KB
+            else:
+                assert c == want, (len(f), level)
+                assert z.Decompress(None, c) == f
 
 
 def test_ctx_go_cases(z, oracle):
@@ -319,12 +360,12 @@ def test_ctx_go_cases(z, oracle):
     comp = c.CompressLevel(None, hello, 1)
     assert comp == oracle.compress(hello, 1)
     assert c.Decompress(None, comp) == hello and c.Decompress(bytearray(2), comp) == hello
-    for level in (1, 2, 3, 4):
+    for level in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
         for size in (1, 10, 100, 1000, 100000):
             d = bytes((i * 7 + (i >> 3)) & 0xFF for i in range(size))
             want = oracle.compress(d, level)
             if isinstance(want, int):
-                continue      # level 4 below 16 KB is ZSTD_greedy
+                continue      # levels 9-10 below 16 KB are ZSTD_btlazy2
             got = c.CompressLevel(bytearray(z.CompressBound(size)), d, level)
             assert bytes(got) == want and c.Decompress(None, bytes(got)) == d
     e = c.CompressLevel(None, b"", 1)
@@ -333,8 +374,8 @@ def test_ctx_go_cases(z, oracle):
         c.Decompress(None, b"")
     big = bytes(130 * 1024)
     assert c.Decompress(bytearray(1), c.CompressLevel(None, big, 1)) == big
-    with pytest.raises(z.api.ZstdError):          # DefaultCompression (5) is ZSTD_greedy: code 40, the Go shim keeps the vendored C
-        c.Compress(None, hello)
+    dflt = c.Compress(None, hello)                # zstd_ctx.go:53-55: DefaultCompression (5)
+    assert dflt == oracle.compress(hello, 5) and c.Decompress(None, dflt) == hello
 
 
 def test_bulk_destination_cases(z, oracle):

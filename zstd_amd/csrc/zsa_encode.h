@@ -21,10 +21,10 @@
 #include "zsa_common.h"
 #include "zsa_params.h"
 
-struct ZsaEncParams { u32 wlog, hlog, mml, tlen, clog, strat; };   // strat: 1 ZSTD_fast, 2 ZSTD_dfast
+struct ZsaEncParams { u32 wlog, hlog, mml, tlen, clog, strat, slog; };   // strat: 1 ZSTD_fast, 2 ZSTD_dfast, 3 greedy, 4 lazy, 5 lazy2
 
 struct ZsaHufCT { u8 nbBits[256]; u16 val[256]; };
-struct ZsaFseCT { u16 nextState[512]; s32 dfs[ZSA_MaxSeq + 1]; u32 dnb[ZSA_MaxSeq + 1]; u32 tableLog; };
+struct ZsaFseCT { u16 nextState[512]; s32 dfs[ZSA_MaxSeq + 1]; u32 dnb[ZSA_MaxSeq + 1]; u32 tableLog; u32 maxSV; };   // maxSV: kept for block-built tables only
 
 struct ZsaCDictDev {            // digested compression dictionary, device resident (zstd_compress.c ZSTD_CDict_s)
     const u8* content; u32 contentSize;   // the part of the dictionary that entered the window (after the entropy header)
@@ -51,9 +51,10 @@ struct ZsaHufNode { u32 count; u16 parent; u8 byte; u8 nbBits; };
 struct ZsaSeqEncScratch { u8 code[3][64]; u16 stBits[3][64]; u8 stNb[3][64]; u32 bitbuf[256]; };
 
 // LDS of one compressing workgroup.  Sized for 16 workgroups per CU (160 KiB / 16): the stages of a block reuse the
-// same bytes.  Only the Huffman tables (literal "repeat" mode) and the block-to-block scalars outlive a block; the FSE
-// sequence tables never do at this strategy (set_repeat is only reachable with dictionary tables, which are re-read
-// from the digest: zstd_compress_sequences.c:180-205).
+// same bytes.  Only the Huffman tables (literal "repeat" mode) and the block-to-block scalars outlive a block.  Below
+// ZSTD_lazy the FSE sequence tables of a block are never used again (set_repeat is only reachable with dictionary
+// tables, which are re-read from the digest: zstd_compress_sequences.c:180-205); from ZSTD_lazy on a later block may
+// price and repeat them (:206-232), so they are parked in the workgroup's global scratch (ZsaEncScratch::park).
 struct ZsaEncShared {
     ZsaHufCT hufPrev, hufNext;
     u32 count[256];                        // histogram of the stage at hand
@@ -258,6 +259,7 @@ ZSA_DEV u32 zsa_parse_fast(u32* hashTable, const ZsaEncParams& P, const u8* base
 
 #include "zsa_parse.h"
 #include "zsa_dfast.h"
+#include "zsa_lazy.h"
 
 // zstd_compress_internal.h:780-793 ZSTD_count_2segments
 ZSA_DEV u32 zsa_count_2segments(const u8* ip, const u8* match, const u8* iEnd, const u8* mEnd, const u8* iStart)
@@ -1061,7 +1063,7 @@ ZSA_DEV u32 zsa_noCompressLiterals(u8* dst, const u8* lit, u32 litSize, int lane
     return flSize + litSize;
 }
 ZSA_DEV u32 zsa_compressLiterals(ZsaEncShared* S, u8* dst, const u8* lit, u32 litSize, u8* tmp,
-                                 int disableLiteralCompression, int suspectUncompressible, int lane)
+                                 int disableLiteralCompression, int suspectUncompressible, u32 strategy, int lane)
 {
     u32 const lhSize = 3 + (litSize >= 1024) + (litSize >= 16384);
     // nextHuf := prevHuf (:153)
@@ -1069,12 +1071,12 @@ ZSA_DEV u32 zsa_compressLiterals(ZsaEncShared* S, u8* dst, const u8* lit, u32 li
     if (lane == 0) S->nextHufRepeat = S->prevHufRepeat;
     wv_sync();
     u32 const prevRepeat = S->prevHufRepeat;
-    u32 const mintc = (prevRepeat == zsa_rep_valid) ? 6 : 64;      // :115-128, strategy fast
+    u32 const mintc = (prevRepeat == zsa_rep_valid) ? 6 : 64;      // :115-128: 8 << min(9 - strategy, 3), strategies fast .. lazy2
     if (disableLiteralCompression || litSize < mintc) return zsa_noCompressLiterals(dst, lit, litSize, lane);
 
     u32 singleStream = litSize < 256;
     if (prevRepeat == zsa_rep_valid && lhSize == 3) singleStream = 1;
-    int const preferRepeat = (litSize <= 1024);
+    int const preferRepeat = (strategy < 4) && (litSize <= 1024);   // :166: strategy < ZSTD_lazy
     u8* const ostart = dst + lhSize;
 
     // ---- huf_compress.c:1298-1406 HUF_compress_internal
@@ -1231,21 +1233,94 @@ ZSA_DEV u32 zsa_MLcode(u32 mlBase)
     if (mlBase < 96) return 40 + ((mlBase - 64) >> 4);
     return 42;
 }
-// zstd_compress_sequences.c:157-236, the `strategy < ZSTD_lazy` branch; serial
-ZSA_DEV u32 zsa_selectEncodingType(u32* repeatMode, u32 mostFrequent, u32 nbSeq, u32 defaultNormLog, int isDefaultAllowed, u32 strategy)
+// zstd_compress_sequences.c:22-45 kInverseProbabilityLog256: floor(-log2(x / 256) * 256) for x in [1, 256), 0 for x == 0
+ZSA_DEV u32 zsa_invProbLog256(u32 x)
 {
+    static const u16 t[256] = {
+        0,    2048, 1792, 1642, 1536, 1453, 1386, 1329, 1280, 1236, 1197, 1162, 1130, 1100, 1073, 1047,
+        1024, 1001, 980,  960,  941,  923,  906,  889,  874,  859,  844,  830,  817,  804,  791,  779,
+        768,  756,  745,  734,  724,  714,  704,  694,  685,  676,  667,  658,  650,  642,  633,  626,
+        618,  610,  603,  595,  588,  581,  574,  567,  561,  554,  548,  542,  535,  529,  523,  517,
+        512,  506,  500,  495,  489,  484,  478,  473,  468,  463,  458,  453,  448,  443,  438,  434,
+        429,  424,  420,  415,  411,  407,  402,  398,  394,  390,  386,  382,  377,  373,  370,  366,
+        362,  358,  354,  350,  347,  343,  339,  336,  332,  329,  325,  322,  318,  315,  311,  308,
+        305,  302,  298,  295,  292,  289,  286,  282,  279,  276,  273,  270,  267,  264,  261,  258,
+        256,  253,  250,  247,  244,  241,  239,  236,  233,  230,  228,  225,  222,  220,  217,  215,
+        212,  209,  207,  204,  202,  199,  197,  194,  192,  190,  187,  185,  182,  180,  178,  175,
+        173,  171,  168,  166,  164,  162,  159,  157,  155,  153,  151,  149,  146,  144,  142,  140,
+        138,  136,  134,  132,  130,  128,  126,  123,  121,  119,  117,  115,  114,  112,  110,  108,
+        106,  104,  102,  100,  98,   96,   94,   93,   91,   89,   87,   85,   83,   82,   80,   78,
+        76,   74,   73,   71,   69,   67,   66,   64,   62,   61,   59,   57,   55,   54,   52,   50,
+        49,   47,   46,   44,   42,   41,   39,   37,   36,   34,   33,   31,   30,   28,   26,   25,
+        23,   22,   20,   19,   17,   16,   14,   13,   11,   10,   8,    7,    5,    4,    2,    1 };
+    return t[x];
+}
+#define ZSA_COST_ERROR 0xFFFFFFFFu   // ERROR(GENERIC) as a cost: above every real one
+// zstd_compress_sequences.c:157-236 ZSTD_selectEncodingType; serial.  Below ZSTD_lazy: threshold rules (:180-205).  From
+// ZSTD_lazy on: cost estimates (:206-232) -- basic = cross entropy against the default distribution (:140-155), repeat =
+// price under the previous block's table `prevCT` (:105-133 with fse.h:494-509; NULL when there is none), compressed =
+// table description (:71-79, written to `wksp` just to be measured) + entropy bound (:85-99).
+ZSA_DEV u32 zsa_selectEncodingType(ZsaEncShared* S, u32* repeatMode, const u32* count, u32 max, u32 mostFrequent, u32 nbSeq,
+                                   int kind, const ZsaFseCT* prevCT, u8* wksp, int isDefaultAllowed, u32 strategy)
+{
+    u32 const defaultNormLog = kind == 1 ? ZSA_OF_DEFAULTNORMLOG : 6;
     if (mostFrequent == nbSeq) {
         *repeatMode = zsa_rep_none;
         if (isDefaultAllowed && nbSeq <= 2) return zsa_set_basic;
         return zsa_set_rle;
     }
-    if (isDefaultAllowed) {
-        u32 const dynamicFse_nbSeq_min = ((1u << defaultNormLog) * (10 - strategy)) >> 3;   // :185
-        if ((*repeatMode == zsa_rep_valid) && (nbSeq < 1000)) return zsa_set_repeat;
-        if ((nbSeq < dynamicFse_nbSeq_min) || (mostFrequent < (nbSeq >> (defaultNormLog - 1)))) {
-            *repeatMode = zsa_rep_none;
-            return zsa_set_basic;
+    if (strategy < 4) {
+        if (isDefaultAllowed) {
+            u32 const dynamicFse_nbSeq_min = ((1u << defaultNormLog) * (10 - strategy)) >> 3;   // :185
+            if ((*repeatMode == zsa_rep_valid) && (nbSeq < 1000)) return zsa_set_repeat;
+            if ((nbSeq < dynamicFse_nbSeq_min) || (mostFrequent < (nbSeq >> (defaultNormLog - 1)))) {
+                *repeatMode = zsa_rep_none;
+                return zsa_set_basic;
+            }
         }
+    } else {
+        u32 basicCost = ZSA_COST_ERROR, repeatCost = ZSA_COST_ERROR, compressedCost;
+        if (isDefaultAllowed) {
+            u32 const shift = 8 - defaultNormLog;
+            u32 cost = 0;
+            for (u32 s = 0; s <= max; ++s) {
+                s32 const n = kind == 0 ? zsa_LL_defaultNorm(s) : (kind == 1 ? zsa_OF_defaultNorm(s) : zsa_ML_defaultNorm(s));
+                u32 const normAcc = (n != -1) ? (u32)n : 1;
+                cost += count[s] * zsa_invProbLog256(normAcc << shift);
+            }
+            basicCost = cost >> 8;
+        }
+        if (*repeatMode != zsa_rep_none && prevCT && prevCT->maxSV >= max) {
+            u32 const tableLog = prevCT->tableLog, badCost = (tableLog + 1) << 8;
+            u32 cost = 0;
+            bool bad = false;
+            for (u32 s = 0; s <= max; ++s) {
+                if (count[s] == 0) continue;
+                u32 const dnb = prevCT->dnb[s];
+                u32 const minNbBits = dnb >> 16;
+                u32 const threshold = (minNbBits + 1) << 16;
+                u32 const deltaFromThreshold = threshold - (dnb + (1u << tableLog));
+                u32 const bitCost = ((minNbBits + 1) << 8) - ((deltaFromThreshold << 8) >> tableLog);
+                if (bitCost >= badCost) { bad = true; break; }
+                cost += count[s] * bitCost;
+            }
+            if (!bad) repeatCost = cost >> 8;
+        }
+        {   u32 const FSELog = kind == 1 ? ZSA_OffFSELog : 9;
+            u32 const tableLog = zsa_fse_optimalTableLog(FSELog, nbSeq, max, 2);
+            u32 NCountCost = 0;
+            if (zsa_fse_normalizeCount(S->norm, tableLog, count, nbSeq, max, nbSeq >= 2048)) NCountCost = ZSA_COST_ERROR >> 3;
+            else NCountCost = zsa_fse_writeNCount(wksp, S->norm, max, tableLog);
+            u32 cost = 0;
+            for (u32 s = 0; s <= max; ++s) {
+                u32 norm = (256 * count[s]) / nbSeq;
+                if (count[s] != 0 && norm == 0) norm = 1;
+                cost += count[s] * zsa_invProbLog256(norm);
+            }
+            compressedCost = (NCountCost << 3) + (cost >> 8);
+        }
+        if (basicCost <= repeatCost && basicCost <= compressedCost) { *repeatMode = zsa_rep_none; return zsa_set_basic; }
+        if (repeatCost <= compressedCost) return zsa_set_repeat;
     }
     *repeatMode = zsa_rep_check;
     return zsa_set_compressed;
@@ -1257,14 +1332,14 @@ ZSA_DEV u32 zsa_buildSeqCTable(ZsaEncShared* S, u8* dst, ZsaFseCT* ct, int kind,
     u32 const FSELog = kind == 1 ? ZSA_OffFSELog : 9;
     switch (type) {
     case zsa_set_rle:
-        ct->tableLog = 0; ct->nextState[0] = 0; ct->nextState[1] = 0; ct->dnb[max] = 0; ct->dfs[max] = 0;
+        ct->tableLog = 0; ct->maxSV = max; ct->nextState[0] = 0; ct->nextState[1] = 0; ct->dnb[max] = 0; ct->dfs[max] = 0;
         *dst = (u8)firstCode;
         return 1;
     case zsa_set_repeat:
         if (dictTable) {
             for (u32 i = 0; i < 512; i++) ct->nextState[i] = dictTable->nextState[i];
             for (u32 i = 0; i <= ZSA_MaxSeq; i++) { ct->dfs[i] = dictTable->dfs[i]; ct->dnb[i] = dictTable->dnb[i]; }
-            ct->tableLog = dictTable->tableLog;
+            ct->tableLog = dictTable->tableLog; ct->maxSV = dictTable->maxSV;
         }
         return 0;
     case zsa_set_basic: {
@@ -1273,7 +1348,7 @@ ZSA_DEV u32 zsa_buildSeqCTable(ZsaEncShared* S, u8* dst, ZsaFseCT* ct, int kind,
         for (u32 s = 0; s <= dmax; s++)
             S->norm[s] = (s16)(kind == 0 ? zsa_LL_defaultNorm(s) : (kind == 1 ? zsa_OF_defaultNorm(s) : zsa_ML_defaultNorm(s)));
         zsa_fse_buildCTable(S, ct->nextState, ct->dfs, ct->dnb, S->norm, dmax, dlog);
-        ct->tableLog = dlog;
+        ct->tableLog = dlog; ct->maxSV = dmax;
         return 0; }
     default: {
         u32 nbSeq_1 = nbSeq;
@@ -1283,7 +1358,7 @@ ZSA_DEV u32 zsa_buildSeqCTable(ZsaEncShared* S, u8* dst, ZsaFseCT* ct, int kind,
         u32 const NCountSize = zsa_fse_writeNCount(dst, S->norm, max, tableLog);
         if (NCountSize == 0) { *fail = 1; return 0; }
         zsa_fse_buildCTable(S, ct->nextState, ct->dfs, ct->dnb, S->norm, max, tableLog);
-        ct->tableLog = tableLog;
+        ct->tableLog = tableLog; ct->maxSV = max;
         return NCountSize; }
     }
 }
@@ -1291,11 +1366,12 @@ ZSA_DEV u32 zsa_buildSeqCTable(ZsaEncShared* S, u8* dst, ZsaFseCT* ct, int kind,
 // Entropy stage of one block: zstd_compress.c:2831-2986.  seq/nbSeq and the gathered literals are in global
 // scratch.  Returns the block body size, 0 for "store raw"; S->err on internal failure.
 ZSA_DEV u32 zsa_entropyCompress(ZsaEncShared* S, const u64* seq, u32 nbSeq, const u8* lit, u32 litSize,
-                                u8* dst, u32 srcSize, u8* tmp, int literalsDisabled, const ZsaCDictDev* cd, u32 strategy, int lane)
+                                u8* dst, u32 srcSize, u8* tmp, int literalsDisabled, const ZsaCDictDev* cd, u32 strategy,
+                                const ZsaFseCT* park, int lane)
 {
     u8* op = dst;
     {   int const suspect = (nbSeq == 0) || (litSize / nbSeq >= 20);
-        op += zsa_compressLiterals(S, op, lit, litSize, tmp, literalsDisabled, suspect, lane);
+        op += zsa_compressLiterals(S, op, lit, litSize, tmp, literalsDisabled, suspect, strategy, lane);
     }
     wv_sync();
     ZSA_PROF(S, lane, 4);
@@ -1330,12 +1406,13 @@ ZSA_DEV u32 zsa_entropyCompress(ZsaEncShared* S, const u64* seq, u32 nbSeq, cons
                 for (u32 s = 0; s <= max; s++) if (S->count[s] > mostFrequent) mostFrequent = S->count[s];
                 u32* const rm = kind == 0 ? &S->nextLL : (kind == 1 ? &S->nextOF : &S->nextML);
                 int const defaultAllowed = kind == 1 ? (max <= ZSA_DefaultMaxOff) : 1;
-                u32 const dlog = kind == 1 ? ZSA_OF_DEFAULTNORMLOG : 6;
-                u32 const type = zsa_selectEncodingType(rm, mostFrequent, nbSeq, dlog, defaultAllowed, strategy);
+                // the table a "repeat" would use: the dictionary's, else (ZSTD_lazy and up) the parked one of the last
+                // compressed block of this frame
+                const ZsaFseCT* const dt = cd ? (kind == 0 ? &cd->ll : (kind == 1 ? &cd->of : &cd->ml)) : (park ? park + kind : (const ZsaFseCT*)0);
+                u32 const type = zsa_selectEncodingType(S, rm, S->count, max, mostFrequent, nbSeq, kind, cd ? (const ZsaFseCT*)0 : dt, tmp, defaultAllowed, strategy);
                 u32 const lastCode = kind == 0 ? zsa_LLcode(zsa_seq_ll(lastSeq)) : (kind == 1 ? zsa_highbit32(zsa_seq_of(lastSeq)) : zsa_MLcode(zsa_seq_ml(lastSeq)));
                 u32 const firstCode = kind == 0 ? zsa_LLcode(zsa_seq_ll(firstSeq)) : (kind == 1 ? zsa_highbit32(zsa_seq_of(firstSeq)) : zsa_MLcode(zsa_seq_ml(firstSeq)));
                 ZsaFseCT* const ct = kind == 0 ? &S->ll : (kind == 1 ? &S->of : &S->ml);
-                const ZsaFseCT* const dt = cd ? (kind == 0 ? &cd->ll : (kind == 1 ? &cd->of : &cd->ml)) : (const ZsaFseCT*)0;
                 u32 fail = 0;
                 u32 const cs = zsa_buildSeqCTable(S, op, ct, kind, type, S->count, max, lastCode, firstCode, nbSeq, dt, &fail);
                 if (fail) S->err = ZSA_GENERIC;
@@ -1487,7 +1564,7 @@ ZSA_DEV void zsa_gatherLiterals(ZsaEncShared* S, const u64* seq, u32 nbSeq, cons
 // ------------------------------------------------------------------ the frame (zstd_compress.c:4392-4632, 5107-5144)
 // hashTable: global memory (per-workgroup scratch, L2-resident), (1 << P.hlog) entries.  scratch: seq (u64 x (blockSizeMax/4 + 8)), lit (128 KiB + 64), tmp (lit-sized x 1.5 + 128).
 // Returns bytes written or (u64)-error (uniform).
-struct ZsaEncScratch { u64* seq; u8* lit; u8* tmp; };
+struct ZsaEncScratch { u64* seq; u8* lit; u8* tmp; ZsaFseCT* park; };   // park: 3 sequence tables (LL, OF, ML) of the last compressed block
 
 ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams& P, const u8* src, u64 srcSize64,
                              u8* dst, u64 dstCapacity, const ZsaEncScratch& W, const ZsaCDictDev* cd, int dictMode)
@@ -1532,8 +1609,9 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
     if (cd && dictMode == zsa_dm_copy) {   // ZSTD_copyCDictTableIntoCCtx: tags removed
         for (u32 i = (u32)lane; i < (1u << P.hlog); i += ZSA_WAVE) hashTable[i] = cd->hashTable[i] >> 8;
     } else {
-        // ZSTD_dfast: the short-hash ("chain") table follows the long one in the same scratch region
-        u32 const cells = (1u << P.hlog) + (P.strat == 2 ? (1u << P.clog) : 0u);
+        // ZSTD_dfast: the short-hash ("chain") table follows the long one in the same scratch region; greedy/lazy/lazy2: the
+        // chain table, or the row finder's tag table (one byte per cell)
+        u32 const cells = (1u << P.hlog) + zsa_auxTableBytes(P.strat, P.wlog, P.hlog, P.clog) / 4u;
         for (u32 i = 4u * (u32)lane; i < cells; i += 4u * ZSA_WAVE) { hashTable[i] = 0; hashTable[i + 1] = 0; hashTable[i + 2] = 0; hashTable[i + 3] = 0; }
     }
     if (cd) {
@@ -1595,6 +1673,16 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
     if (!cd && P.strat == 1) { u32 const bits = 32u - (u32)__builtin_clz(srcSize + 2u); if (bits <= 26) fpPosBits = bits; }
     int const literalsDisabled = (P.strat == 1) && (P.tlen > 0);   // zstd_compress_internal.h:605-618
     u32 const maxDist = 1u << P.wlog;
+    ZsaLazyCtx LZ;   // greedy / lazy / lazy2 (zsa_lazy.h): match-finder state that lives across the blocks of the frame
+    LZ.hashTable = hashTable; LZ.chainTable = hashTable + (1u << P.hlog); LZ.tagTable = (u8*)(hashTable + (1u << P.hlog));
+    LZ.base = Wn.base; LZ.hlog = P.hlog; LZ.clog = P.clog; LZ.wlog = P.wlog; LZ.slog = P.slog;
+    LZ.mls = P.mml < 4 ? 4 : (P.mml > 6 ? 6 : P.mml);
+    LZ.rowLog = P.slog < 4 ? 4 : (P.slog > 6 ? 6 : P.slog);
+    LZ.rowHashLog = P.hlog - LZ.rowLog;                             // zstd_compress.c:1991-1995
+    LZ.useRow = zsa_useRowFinder(P.strat, P.wlog);
+    LZ.lowLimit = Wn.lowLimit; LZ.nextToUpdate = Wn.dictLimit;      // zstd_compress.c:4596-4600
+    LZ.lazySkipping = 0;
+    u32 tablesBuilt = 0;
     u32 remaining = srcSize;
     const u8* ip = src;
     int isFirstBlock = 1;
@@ -1614,9 +1702,16 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
                 Wn.loadedDictEnd = 0; Wn.dms = nullptr;
             }
         }
+        if (LZ.nextToUpdate < Wn.lowLimit) LZ.nextToUpdate = Wn.lowLimit;   // zstd_compress.c:4427
+        LZ.lowLimit = Wn.lowLimit;
         u32 cSize = 0;
+        tablesBuilt = 0;
         ZSA_PROF(S, lane, 0);
         if (blockSize >= 7) {   // zstd_compress.c:3156
+            {   // :3174-3181 limited update after a very long match
+                u32 const curr = (u32)(ip - Wn.base);
+                if (curr > LZ.nextToUpdate + 384) { u32 const gap = curr - LZ.nextToUpdate - 384; LZ.nextToUpdate = curr - (gap < 192 ? gap : 192); }
+            }
             bool const dictParse = (Wn.lowLimit < Wn.dictLimit) || (Wn.dms != nullptr);
             if (dictParse && lane == 0) {   // dictionary variants: serial (small payloads; many frames in flight instead)
                 u32 rep[3] = { S->prevRep[0], S->prevRep[1], S->prevRep[2] };
@@ -1632,7 +1727,13 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
                 wv_sync();
                 u32 rep[3] = { S->prevRep[0], S->prevRep[1], S->prevRep[2] };
                 u32 lastLL = 0, nbSeq;
-                if (P.strat == 2) {   // ZSTD_dfast (never with a dictionary here): serial for now, zsa_dfast.h
+                if (P.strat >= 3) {   // greedy / lazy / lazy2 (never with a dictionary here): serial for now, zsa_lazy.h
+                    nbSeq = 0;
+                    u32 ntu = LZ.nextToUpdate;
+                    if (lane == 0) { nbSeq = zsa_parse_lazy(LZ, Wn.dictLimit, ip, blockSize, P.strat - 3, rep, W.seq, &lastLL); ntu = LZ.nextToUpdate; }
+                    nbSeq = wv_shfl(nbSeq, 0); lastLL = wv_shfl(lastLL, 0); LZ.nextToUpdate = wv_shfl(ntu, 0);
+                    rep[0] = wv_shfl(rep[0], 0); rep[1] = wv_shfl(rep[1], 0);
+                } else if (P.strat == 2) {   // ZSTD_dfast (never with a dictionary here): serial for now, zsa_dfast.h
                     nbSeq = 0;
                     if (lane == 0) nbSeq = zsa_parse_dfast(hashTable, hashTable + (1u << P.hlog), P, Wn.base, Wn.dictLimit, ip, blockSize, rep, W.seq, &lastLL);
                     nbSeq = wv_shfl(nbSeq, 0); lastLL = wv_shfl(lastLL, 0);
@@ -1663,8 +1764,10 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
             zsa_gatherLiterals(S, W.seq, nbSeq, ip, blockSize, lastLL, W.lit, lane);
             wv_sync();
             ZSA_PROF(S, lane, 2);
-            cSize = zsa_entropyCompress(S, W.seq, nbSeq, W.lit, litSize, op + 3, blockSize, W.tmp, literalsDisabled, cd, P.strat, lane);
+            cSize = zsa_entropyCompress(S, W.seq, nbSeq, W.lit, litSize, op + 3, blockSize, W.tmp, literalsDisabled, cd, P.strat,
+                                        (P.strat >= 4 && !cd) ? W.park : (const ZsaFseCT*)0, lane);
             if (S->err) return ZSA_ERR(S->err);
+            tablesBuilt = nbSeq != 0;
             if (!isFirstBlock && cSize < 25) {   // zstd_compress.c:4258-4269 (ZSTD_isRLE :3413-3433)
                 u32 diff = 0;
                 u8 const b0 = ip[0];
@@ -1678,6 +1781,13 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
             S->prevHufRepeat = S->nextHufRepeat; S->prevLL = S->nextLL; S->prevOF = S->nextOF; S->prevML = S->nextML;
         }
         if (cSize > 1) for (u32 i = (u32)lane; i < 256; i += ZSA_WAVE) { S->hufPrev.nbBits[i] = S->hufNext.nbBits[i]; S->hufPrev.val[i] = S->hufNext.val[i]; }
+        if (cSize > 1 && tablesBuilt && P.strat >= 4 && !cd && !lastBlock) {
+            // a later block may price or repeat these tables (zstd_compress_sequences.c:206-232): park them before the next
+            // parse reuses their LDS.  A block without sequences leaves the parked ones in place (zstd_compress.c:2901-2906).
+            const u32* const from[3] = { (const u32*)&S->ll, (const u32*)&S->of, (const u32*)&S->ml };
+            for (int k = 0; k < 3; k++)
+                for (u32 i = (u32)lane; i < sizeof(ZsaFseCT) / 4; i += ZSA_WAVE) ((u32*)(W.park + k))[i] = from[k][i];
+        }
         wv_sync();
         if (lane == 0 && S->prevOF == zsa_rep_valid) S->prevOF = zsa_rep_check;   // :4279-4280
         if (cSize == 0) {   // ZSTD_noCompressBlock, zstd_compress_internal.h:569-579

@@ -1,0 +1,294 @@
+// zsa_lazy.h -- the greedy / lazy / lazy2 parses without a dictionary (zstd_lazy.c:1493-1757), with the two match finders
+// libzstd 1.5.5 pairs them with: hash chain (windowLog <= 14, :617-761) and row hash (windowLog > 14, :764-1313;
+// zstd_compress.c:236-252 picks).  These are levels 5..12 where clevels.h has a greedy/lazy/lazy2 row -- level 5 is the
+// default of the reference's Compress() (zstd.go:23,90-92).
+//
+// Tables, all in the workgroup's global scratch: hashTable (1 << hashLog cells), then either the chain table
+// (1 << chainLog cells) or the row finder's tag table (1 << hashLog bytes; byte 0 of every row is the row's head).
+//
+// First version: the chain is walked by one lane (the frames of a launch still run 16 per CU), like zsa_dfast.h.  Two
+// things of the reference are not restated because they cannot change a result (argued in oracle/zo_lazy.inc, which is
+// pinned to the reference build): the row finder's 8-entry hash cache -- hashes are taken at the point of use; its one
+// visible effect, the parser stopping 8 bytes earlier, is kept -- and the SIMD forms of the tag comparison, replaced by a
+// SWAR byte-equality mask over the row's 16/32/64 tag bytes.
+// Included by zsa_encode.h.
+#pragma once
+
+// zstd_compress.c:1916-1927: the hash salt of a fresh context, ZSTD_advanceHashSalt on hashSalt = hashSaltEntropy = 0
+constexpr u64 zsa_bitmix_c(u64 val, u64 len)
+{
+    val ^= ((val >> 49) | (val << 15)) ^ ((val >> 24) | (val << 40));
+    val *= 0x9FB21C651E98DF25ULL;
+    val ^= (val >> 35) + len;
+    val *= 0x9FB21C651E98DF25ULL;
+    return val ^ (val >> 28);
+}
+constexpr u64 ZSA_FRESH_HASH_SALT = zsa_bitmix_c(0, 8) ^ zsa_bitmix_c(0, 4);
+
+// zstd_compress_internal.h:849-863 ZSTD_hashPtrSalted, mls in 4..6; v = MEM_readLE64(p)
+ZSA_DEV u32 zsa_hash_salted(u64 v, u32 hBits, u32 mls, u64 salt)
+{
+    if (mls == 5) return (u32)((((v << (64 - 40)) * 889523592379ULL) ^ salt) >> (64 - hBits));
+    if (mls == 6) return (u32)((((v << (64 - 48)) * 227718039650203ULL) ^ salt) >> (64 - hBits));
+    return (((u32)v * 2654435761U) ^ (u32)salt) >> (32 - hBits);
+}
+
+struct ZsaLazyCtx {
+    u32* hashTable; u32* chainTable; u8* tagTable;
+    const u8* base;
+    u32 hlog, clog, wlog, slog, mls, rowLog, rowHashLog;
+    u32 lowLimit;            // window.lowLimit (no dictionary: loadedDictEnd == 0)
+    u32 nextToUpdate;        // first index not yet entered into the tables; lives across the blocks of a frame
+    u32 lazySkipping;
+    bool useRow;
+};
+
+// ---------------------------------------------------------------- hash chain
+// zstd_lazy.c:621-646 ZSTD_insertAndFindFirstIndex_internal
+ZSA_DEV u32 zsa_hc_insertAndFind(ZsaLazyCtx& C, const u8* ip, u64 vip)
+{
+    u32 const chainMask = (1u << C.clog) - 1u;
+    u32 const target = (u32)(ip - C.base);
+    u32 idx = C.nextToUpdate;
+    while (idx < target) {
+        u32 const h = zsa_hash(wv_ldg64(C.base + idx), C.hlog, C.mls);
+        wv_stg_cell(C.chainTable + (idx & chainMask), wv_ldg_cell(C.hashTable + h));
+        wv_stg_cell(C.hashTable + h, idx);
+        idx++;
+        if (C.lazySkipping) break;
+    }
+    C.nextToUpdate = target;
+    return wv_ldg_cell(C.hashTable + zsa_hash(vip, C.hlog, C.mls));
+}
+// zstd_lazy.c:655-761 ZSTD_HcFindBestMatch, noDict.  Returns the best length (3 = none), offBase in *offBasePtr.
+ZSA_DEV u32 zsa_hc_findBestMatch(ZsaLazyCtx& C, const u8* ip, const u8* iLimit, u32* offBasePtr)
+{
+    u32 const chainSize = 1u << C.clog, chainMask = chainSize - 1u;
+    u32 const curr = (u32)(ip - C.base);
+    u32 const maxDistance = 1u << C.wlog;
+    u32 const lowLimit = (curr - C.lowLimit > maxDistance) ? curr - maxDistance : C.lowLimit;
+    u32 const minChain = curr > chainSize ? curr - chainSize : 0;
+    u32 nbAttempts = 1u << C.slog;
+    u32 ml = 4 - 1;
+    u64 const vip = wv_ldg64(ip);
+    u32 matchIndex = zsa_hc_insertAndFind(C, ip, vip);
+    for (; (matchIndex >= lowLimit) & (nbAttempts > 0); nbAttempts--) {
+        u32 currentMl = 0;
+        const u8* const match = C.base + matchIndex;
+        u32 const next = wv_ldg_cell(C.chainTable + (matchIndex & chainMask));   // rides along with the byte check
+        u32 const mine = ml == 3 ? (u32)vip : wv_ldg32(ip + ml - 3);
+        if (wv_ldg32(match + ml - 3) == mine) currentMl = zsa_dfast_count(ip, match, iLimit);
+        if (currentMl > ml) {
+            ml = currentMl;
+            *offBasePtr = (curr - matchIndex) + 3;
+            if (ip + currentMl == iLimit) break;
+        }
+        if (matchIndex <= minChain) break;
+        matchIndex = next;
+    }
+    return ml;
+}
+
+// ---------------------------------------------------------------- row hash
+// zstd_lazy.c:786-791 ZSTD_row_nextIndex + :867-890 one position of ZSTD_row_update_internalImpl
+ZSA_DEV void zsa_row_put(ZsaLazyCtx& C, u32 relRow, u32 tag, u32 idx, u32 rowMask)
+{
+    u8* const tagRow = C.tagTable + relRow;
+    u32 next = (wv_ldg8(tagRow) - 1u) & rowMask;
+    next += (next == 0) ? rowMask : 0;
+    wv_stg8(tagRow, next);
+    wv_stg8(tagRow + next, tag);
+    wv_stg_cell(C.hashTable + relRow + next, idx);
+}
+ZSA_DEV void zsa_row_insert(ZsaLazyCtx& C, u32 idx, u32 rowMask)
+{
+    u32 const hash = zsa_hash_salted(wv_ldg64(C.base + idx), C.rowHashLog + 8, C.mls, ZSA_FRESH_HASH_SALT);
+    zsa_row_put(C, (hash >> 8) << C.rowLog, hash & 0xFF, idx, rowMask);
+}
+// zstd_lazy.c:896-923 ZSTD_row_update_internal (useCache == 1): long gaps are indexed at their two ends only
+ZSA_DEV void zsa_row_update(ZsaLazyCtx& C, const u8* ip, u32 rowMask)
+{
+    u32 idx = C.nextToUpdate;
+    u32 const target = (u32)(ip - C.base);
+    if (target - idx > 384) {
+        u32 const bound = idx + 96;
+        for (; idx < bound; idx++) zsa_row_insert(C, idx, rowMask);
+        idx = target - 32;
+    }
+    for (; idx < target; idx++) zsa_row_insert(C, idx, rowMask);
+    C.nextToUpdate = target;
+}
+// zstd_lazy.c:1120-1313 ZSTD_RowFindBestMatch, noDict
+ZSA_DEV u32 zsa_row_findBestMatch(ZsaLazyCtx& C, const u8* ip, const u8* iLimit, u32* offBasePtr)
+{
+    u32 const curr = (u32)(ip - C.base);
+    u32 const maxDistance = 1u << C.wlog;
+    u32 const lowLimit = (curr - C.lowLimit > maxDistance) ? curr - maxDistance : C.lowLimit;
+    u32 const rowEntries = 1u << C.rowLog, rowMask = rowEntries - 1u;
+    u32 nbAttempts = 1u << (C.slog < C.rowLog ? C.slog : C.rowLog);
+    u32 ml = 4 - 1;
+    u32 matchBuffer[64];
+    u32 numMatches = 0;
+
+    if (!C.lazySkipping) zsa_row_update(C, ip, rowMask);   // :1184-1186
+    else C.nextToUpdate = curr;                            // :1187-1193
+    u64 const vip = wv_ldg64(ip);
+    u32 const hash = zsa_hash_salted(vip, C.rowHashLog + 8, C.mls, ZSA_FRESH_HASH_SALT);
+    u32 const relRow = (hash >> 8) << C.rowLog;
+    u32 const tag = hash & 0xFF;
+    u32* const row = C.hashTable + relRow;
+    u8* const tagRow = C.tagTable + relRow;
+    // :1040-1102 the match mask: bit p set iff tagRow[p] == tag (rows are rowEntries-aligned; all loads in one round trip)
+    u64 eq = 0;
+    u32 head = 0;
+    {   u64 const splat = (u64)tag * 0x0101010101010101ULL;
+        u32 const nW = rowEntries >> 3;
+        for (u32 w = 0; w < nW; w++) {
+            u64 const t = wv_ldg64(tagRow + 8u * w);
+            if (w == 0) head = (u32)t & rowMask;
+            u64 const x = t ^ splat;                                                    // zero bytes are the equal ones
+            u64 const nz = (((x & 0x7F7F7F7F7F7F7F7FULL) + 0x7F7F7F7F7F7F7F7FULL) | x) & 0x8080808080808080ULL;
+            u64 const z = (nz ^ 0x8080808080808080ULL) >> 7;                            // 0x01 in every equal byte
+            eq |= ((z * 0x0102040810204080ULL) >> 56) << (8u * w);
+        }
+    }
+    // :1205-1222: candidates from the newest (head) to the oldest; position 0 holds the head byte, not an entry
+    {   u64 rot = head ? ((eq >> head) | (eq << (rowEntries - head))) : eq;
+        if (rowEntries < 64) rot &= (((u64)1 << rowEntries) - 1u);
+        for (; rot && nbAttempts > 0; rot &= rot - 1) {
+            u32 const matchPos = (head + (u32)__builtin_ctzll(rot)) & rowMask;
+            if (matchPos == 0) continue;
+            u32 const matchIndex = wv_ldg_cell(row + matchPos);
+            if (matchIndex < lowLimit) break;
+            matchBuffer[numMatches++] = matchIndex;
+            --nbAttempts;
+        }
+    }
+    zsa_row_put(C, relRow, tag, C.nextToUpdate++, rowMask);   // :1224-1230 the current position enters the row right away
+    for (u32 k = 0; k < numMatches; ++k) {                   // :1232-1258
+        u32 const matchIndex = matchBuffer[k];
+        u32 currentMl = 0;
+        const u8* const match = C.base + matchIndex;
+        u32 const mine = ml == 3 ? (u32)vip : wv_ldg32(ip + ml - 3);
+        if (wv_ldg32(match + ml - 3) == mine) currentMl = zsa_dfast_count(ip, match, iLimit);
+        if (currentMl > ml) {
+            ml = currentMl;
+            *offBasePtr = (curr - matchIndex) + 3;
+            if (ip + currentMl == iLimit) break;
+        }
+    }
+    return ml;
+}
+
+ZSA_DEV u32 zsa_searchMax(ZsaLazyCtx& C, const u8* ip, const u8* iend, u32* offBasePtr)
+{   // zstd_lazy.c:1466-1487
+    return C.useRow ? zsa_row_findBestMatch(C, ip, iend, offBasePtr) : zsa_hc_findBestMatch(C, ip, iend, offBasePtr);
+}
+
+// depth 0 = greedy, 1 = lazy, 2 = lazy2 (zstd_lazy.c:1493-1757).  Appends packed sequences to seqOut, returns their
+// number; rep[] and *lastLL are updated.  Runs on one lane.
+ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcSize, u32 depth, u32 rep[3], u64* seqOut, u32* lastLL)
+{
+    const u8* const istart = src;
+    const u8* ip = istart + wv_vzero();   // per-lane state (zsa_wave_hip.h)
+    const u8* anchor = istart;
+    const u8* const iend = istart + srcSize;
+    s32 const margin = C.useRow ? 8 + 8 : 8;             // :1505 (the row finder's hash cache looks 8 positions ahead)
+    const u8* const prefixLowest = C.base + dictLimit;
+    u32 offset_1 = rep[0], offset_2 = rep[1], saved1 = 0, saved2 = 0, nbSeq = 0;
+#define ZSA_BEFORE_LIMIT(p) ((s32)(iend - (p)) > margin)      /* p <  ilimit */
+#define ZSA_UPTO_LIMIT(p)   ((s32)(iend - (p)) >= margin)     /* p <= ilimit */
+#define ZSA_HB(x) (31u - (u32)__builtin_clz((u32)(x)))
+
+    ip += (ip == prefixLowest);
+    {   u32 const curr = (u32)(ip - C.base);
+        u32 const maxDistance = 1u << C.wlog;
+        u32 const windowLow = (curr - dictLimit > maxDistance) ? curr - maxDistance : dictLimit;   // ZSTD_getLowestPrefixIndex
+        u32 const maxRep = curr - windowLow;
+        if (offset_2 > maxRep) { saved2 = offset_2; offset_2 = 0; }
+        if (offset_1 > maxRep) { saved1 = offset_1; offset_1 = 0; }
+    }
+    C.lazySkipping = 0;
+
+    while (ZSA_BEFORE_LIMIT(ip)) {
+        u32 matchLength = 0;
+        u32 offBase = 1;   // REPCODE1_TO_OFFBASE
+        const u8* start = ip + 1;
+        bool storeNow = false;
+
+        // :1578-1582 repcode at ip+1
+        if ((offset_1 > 0) && (wv_ldg32(ip + 1 - offset_1) == wv_ldg32(ip + 1))) {
+            matchLength = zsa_dfast_count(ip + 1 + 4, ip + 1 + 4 - offset_1, iend) + 4;
+            if (depth == 0) storeNow = true;
+        }
+        if (!storeNow) {
+            {   u32 offbaseFound = 999999999;   // :1585-1589
+                u32 const ml2 = zsa_searchMax(C, ip, iend, &offbaseFound);
+                if (ml2 > matchLength) { matchLength = ml2; start = ip; offBase = offbaseFound; }
+            }
+            if (matchLength < 4) {   // :1591-1603
+                u32 const step = ((u32)(ip - anchor) >> 8) + 1;   // kSearchStrength
+                ip += step;
+                C.lazySkipping = step > 8;                        // kLazySkippingStep
+                continue;
+            }
+            if (depth >= 1)
+            while (ZSA_BEFORE_LIMIT(ip)) {   // :1606-1678
+                ip++;
+                if ((offBase) && ((offset_1 > 0) && (wv_ldg32(ip) == wv_ldg32(ip - offset_1)))) {
+                    u32 const mlRep = zsa_dfast_count(ip + 4, ip + 4 - offset_1, iend) + 4;
+                    s32 const gain2 = (s32)(mlRep * 3);
+                    s32 const gain1 = (s32)(matchLength * 3 - ZSA_HB(offBase) + 1);
+                    if ((mlRep >= 4) && (gain2 > gain1)) { matchLength = mlRep; offBase = 1; start = ip; }
+                }
+                {   u32 ofbCandidate = 999999999;
+                    u32 const ml2 = zsa_searchMax(C, ip, iend, &ofbCandidate);
+                    s32 const gain2 = (s32)(ml2 * 4 - ZSA_HB(ofbCandidate));
+                    s32 const gain1 = (s32)(matchLength * 4 - ZSA_HB(offBase) + 4);
+                    if ((ml2 >= 4) && (gain2 > gain1)) { matchLength = ml2; offBase = ofbCandidate; start = ip; continue; }
+                }
+                if ((depth == 2) && ZSA_BEFORE_LIMIT(ip)) {
+                    ip++;
+                    if ((offBase) && ((offset_1 > 0) && (wv_ldg32(ip) == wv_ldg32(ip - offset_1)))) {
+                        u32 const mlRep = zsa_dfast_count(ip + 4, ip + 4 - offset_1, iend) + 4;
+                        s32 const gain2 = (s32)(mlRep * 4);
+                        s32 const gain1 = (s32)(matchLength * 4 - ZSA_HB(offBase) + 1);
+                        if ((mlRep >= 4) && (gain2 > gain1)) { matchLength = mlRep; offBase = 1; start = ip; }
+                    }
+                    {   u32 ofbCandidate = 999999999;
+                        u32 const ml2 = zsa_searchMax(C, ip, iend, &ofbCandidate);
+                        s32 const gain2 = (s32)(ml2 * 4 - ZSA_HB(ofbCandidate));
+                        s32 const gain1 = (s32)(matchLength * 4 - ZSA_HB(offBase) + 7);
+                        if ((ml2 >= 4) && (gain2 > gain1)) { matchLength = ml2; offBase = ofbCandidate; start = ip; continue; }
+                    }
+                }
+                break;
+            }
+            if (offBase > 3) {   // :1685-1698 catch up
+                u32 const off = offBase - 3;
+                while (((start > anchor) & (start - off > prefixLowest)) && (wv_ldg8(start - 1) == wv_ldg8(start - off - 1))) { start--; matchLength++; }
+                offset_2 = offset_1; offset_1 = off;
+            }
+        }
+        // :1700-1704 _storeSequence
+        seqOut[nbSeq++] = zsa_packseq((u32)(start - anchor), matchLength - ZSA_MINMATCH, offBase);
+        anchor = ip = start + matchLength;
+        C.lazySkipping = 0;   // :1705-1711
+        // :1735-1745 immediate repcode
+        while ((ZSA_UPTO_LIMIT(ip) & (offset_2 > 0)) && (wv_ldg32(ip) == wv_ldg32(ip - offset_2))) {
+            matchLength = zsa_dfast_count(ip + 4, ip + 4 - offset_2, iend) + 4;
+            { u32 const t = offset_2; offset_2 = offset_1; offset_1 = t; }
+            seqOut[nbSeq++] = zsa_packseq(0, matchLength - ZSA_MINMATCH, 1);
+            ip += matchLength;
+            anchor = ip;
+        }
+    }
+#undef ZSA_BEFORE_LIMIT
+#undef ZSA_UPTO_LIMIT
+#undef ZSA_HB
+    saved2 = ((saved1 != 0) && (offset_1 != 0)) ? saved1 : saved2;   // :1747-1753
+    rep[0] = offset_1 ? offset_1 : saved1;
+    rep[1] = offset_2 ? offset_2 : saved2;
+    *lastLL = (u32)(iend - anchor);
+    return nbSeq;
+}

@@ -26,10 +26,13 @@
 #define ZSA_LIT_CAP   (ZSA_BLOCKSIZE_MAX + 128)
 #define ZSA_TMP_CAP   (ZSA_BLOCKSIZE_MAX * 3 / 2 + 512)
 #ifndef ZSA_HT_BYTES
-#define ZSA_HT_BYTES   ((size_t)2 << 20)                     // match table(s) of the frame in flight: 4 << hashLog bytes, plus
-                                                            // 4 << chainLog for ZSTD_dfast (level 4 at > 256 KB: 1 MiB + 1 MiB)
+#define ZSA_HT_BYTES   ((size_t)5 << 20)                     // match table(s) of the frame in flight: 4 << hashLog bytes, plus
+                                                            // 4 << chainLog for ZSTD_dfast (level 4 at > 256 KB: 1 MiB + 1 MiB), the
+                                                            // hash chain or the row finder's tags for greedy/lazy/lazy2 (levels 7-8
+                                                            // at > 256 KB: 4 MiB + 1 MiB)
 #endif
-#define ZSA_ENC_SCRATCH_BYTES ((size_t)ZSA_SEQ_CAP * 8 + ZSA_LIT_CAP + ZSA_TMP_CAP + ZSA_HT_BYTES)
+#define ZSA_PARK_BYTES ((3 * sizeof(ZsaFseCT) + 255) / 256 * 256)   // sequence tables of the last compressed block (ZSTD_lazy and up)
+#define ZSA_ENC_SCRATCH_BYTES ((size_t)ZSA_SEQ_CAP * 8 + ZSA_LIT_CAP + ZSA_TMP_CAP + ZSA_PARK_BYTES + ZSA_HT_BYTES)
 #define ZSA_DEC_SCRATCH_BYTES ((size_t)((ZSA_DEC_WKSP_BYTES + 255) / 256 * 256))
 
 struct ZsaLaunchDict { const ZsaCDictDev* cd; const ZsaDDictDev* dd; };
@@ -67,7 +70,8 @@ zsa_k_compress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ result
     u8* const wg = scratch + (size_t)blockIdx.x * ZSA_ENC_SCRATCH_BYTES;
     ZsaEncScratch W;
     W.seq = (u64*)wg; W.lit = wg + (size_t)ZSA_SEQ_CAP * 8; W.tmp = W.lit + ZSA_LIT_CAP;
-    u32* const zsa_hashTable = (u32*)(W.tmp + ZSA_TMP_CAP);
+    W.park = (ZsaFseCT*)(W.tmp + ZSA_TMP_CAP);
+    u32* const zsa_hashTable = (u32*)(W.tmp + ZSA_TMP_CAP + ZSA_PARK_BYTES);
     for (;;) {
         if (threadIdx.x == 0) nextFrame = atomicAdd(counter, 1u);
         __syncthreads();
@@ -81,11 +85,11 @@ zsa_k_compress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ result
         int dictMode = zsa_dm_none;
         int const bad = cd ? zsa_resolveCDictUse(&cp, &dictMode, cd->cp, cd->level, cd->dictSize, d.srcSize)
                            : zsa_resolveCParams(&cp, level, d.srcSize, 0, zsa_cpm_noAttachDict);
-        // strategies: ZSTD_fast, and ZSTD_dfast without a dictionary; the tables must fit the workgroup's scratch
-        size_t const tableBytes = ((size_t)4 << cp.hlog) + (cp.strat == 2 ? ((size_t)4 << cp.clog) : 0);
-        if (bad || !(cp.strat == 1 || (cp.strat == 2 && !cd)) || tableBytes > ZSA_HT_BYTES) r = ZSA_ERR(ZSA_parameter_unsupported);
+        // strategies: ZSTD_fast, and ZSTD_dfast .. ZSTD_lazy2 without a dictionary; the tables must fit the workgroup's scratch
+        size_t const tableBytes = bad ? 0 : ((size_t)4 << cp.hlog) + zsa_auxTableBytes(cp.strat, cp.wlog, cp.hlog, cp.clog);
+        if (bad || !(cp.strat == 1 || (cp.strat >= 2 && cp.strat <= 5 && !cd)) || tableBytes > ZSA_HT_BYTES) r = ZSA_ERR(ZSA_parameter_unsupported);
         else {
-            ZsaEncParams P; P.wlog = cp.wlog; P.hlog = cp.hlog; P.mml = cp.mml; P.tlen = cp.tlen; P.clog = cp.clog; P.strat = cp.strat;
+            ZsaEncParams P; P.wlog = cp.wlog; P.hlog = cp.hlog; P.mml = cp.mml; P.tlen = cp.tlen; P.clog = cp.clog; P.strat = cp.strat; P.slog = cp.slog;
             r = zsa_encode_frame(&S, zsa_hashTable, P, d.src, d.srcSize, d.dst, d.dstCapacity, W, cd, dictMode);
         }
         if (threadIdx.x == 0) results[f] = r;

@@ -1,6 +1,6 @@
 // zsa_params.h -- compression-parameter resolution, usable from host and device code.
 // Restates ZSTD_getCParams_internal + ZSTD_adjustCParams_internal (zstd_compress.c:6935-6983, 1427-1555) for the
-// clevels.h rows whose strategy this engine implements (ZSTD_fast, ZSTD_dfast).
+// clevels.h rows whose strategy this engine implements (ZSTD_fast, ZSTD_dfast, ZSTD_greedy, ZSTD_lazy, ZSTD_lazy2).
 #pragma once
 #include "zsa_common.h"
 
@@ -10,19 +10,45 @@ enum { zsa_cpm_noAttachDict = 0, zsa_cpm_attachDict = 1, zsa_cpm_createCDict = 2
 
 ZSA_HD u32 zsa_hb32(u32 v) { return 31u - (u32)__builtin_clz(v); }
 
+#define ZSA_MAX_LEVEL 12
 ZSA_HD ZsaCParams zsa_levelRow(u32 tableID, u32 row)
-{   // clevels.h:26-131, rows {negative-level base, 1, 2, 3, 4}; strategy 0 marks a row outside this engine (greedy)
-    const u8 t[4][5][7] = {
-        { {19,12,13,1,6,1,1}, {19,13,14,1,7,0,1}, {20,15,16,1,6,0,1}, {21,16,17,1,5,0,2}, {21,18,18,1,5,0,2} },
-        { {18,12,13,1,5,1,1}, {18,13,14,1,6,0,1}, {18,14,14,1,5,0,2}, {18,16,16,1,4,0,2}, {18,16,17,3,5,2,0} },
-        { {17,12,12,1,5,1,1}, {17,12,13,1,6,0,1}, {17,13,15,1,5,0,1}, {17,15,16,2,5,0,2}, {17,17,17,2,4,0,2} },
-        { {14,12,13,1,5,1,1}, {14,14,15,1,5,0,1}, {14,14,15,1,4,0,1}, {14,14,15,2,4,0,2}, {14,14,14,4,4,2,0} } };
+{   // clevels.h:26-131, rows {negative-level base, 1 .. 12}.  Strategies: 1 fast, 2 dfast, 3 greedy, 4 lazy, 5 lazy2;
+    // 6 btlazy2 and 7 btopt rows are outside this engine
+    const u8 t[4][ZSA_MAX_LEVEL + 1][7] = {
+        {   // > 256 KB
+            {19,12,13,1,6,1,1}, {19,13,14,1,7,0,1}, {20,15,16,1,6,0,1}, {21,16,17,1,5,0,2}, {21,18,18,1,5,0,2},
+            {21,18,19,3,5,2,3}, {21,18,19,3,5,4,4}, {21,19,20,4,5,8,4}, {21,19,20,4,5,16,5}, {22,20,21,4,5,16,5},
+            {22,21,22,5,5,16,5}, {22,21,22,6,5,16,5}, {22,22,23,6,5,32,5} },
+        {   // <= 256 KB
+            {18,12,13,1,5,1,1}, {18,13,14,1,6,0,1}, {18,14,14,1,5,0,2}, {18,16,16,1,4,0,2}, {18,16,17,3,5,2,3},
+            {18,17,18,5,5,2,3}, {18,18,19,3,5,4,4}, {18,18,19,4,4,4,4}, {18,18,19,4,4,8,5}, {18,18,19,5,4,8,5},
+            {18,18,19,6,4,8,5}, {18,18,19,5,4,12,6}, {18,19,19,7,4,12,6} },
+        {   // <= 128 KB
+            {17,12,12,1,5,1,1}, {17,12,13,1,6,0,1}, {17,13,15,1,5,0,1}, {17,15,16,2,5,0,2}, {17,17,17,2,4,0,2},
+            {17,16,17,3,4,2,3}, {17,16,17,3,4,4,4}, {17,16,17,3,4,8,5}, {17,16,17,4,4,8,5}, {17,16,17,5,4,8,5},
+            {17,16,17,6,4,8,5}, {17,17,17,5,4,8,6}, {17,18,17,7,4,12,6} },
+        {   // <= 16 KB
+            {14,12,13,1,5,1,1}, {14,14,15,1,5,0,1}, {14,14,15,1,4,0,1}, {14,14,15,2,4,0,2}, {14,14,14,4,4,2,3},
+            {14,14,14,3,4,4,4}, {14,14,14,4,4,8,5}, {14,14,14,6,4,8,5}, {14,14,14,8,4,8,5}, {14,15,14,5,4,8,6},
+            {14,15,14,9,4,8,6}, {14,15,14,3,4,12,7}, {14,15,14,4,3,24,7} } };
     ZsaCParams c;
     c.wlog = t[tableID][row][0]; c.clog = t[tableID][row][1]; c.hlog = t[tableID][row][2]; c.slog = t[tableID][row][3];
     c.mml = t[tableID][row][4]; c.tlen = t[tableID][row][5]; c.strat = t[tableID][row][6];
     return c;
 }
-// zstd_compress.c:1427-1555 ZSTD_dictAndWindowLog + ZSTD_adjustCParams_internal (strategies fast/dfast)
+// zstd_compress.c:223-252: greedy/lazy/lazy2 use the row-hash match finder when windowLog > 14 (a SIMD build, as the
+// reference's x86-64 cgo build is), else the hash chain
+ZSA_HD bool zsa_useRowFinder(u32 strat, u32 wlog) { return strat >= 3 && strat <= 5 && wlog > 14; }
+// bytes of the table that follows the hash table in a frame's scratch: ZSTD_dfast's short-hash table, the hash chain, or
+// the row finder's tags (zstd_compress.c:1938-1996)
+ZSA_HD u32 zsa_auxTableBytes(u32 strat, u32 wlog, u32 hlog, u32 clog)
+{
+    if (strat < 2) return 0;
+    if (zsa_useRowFinder(strat, wlog)) return 1u << hlog;
+    return 4u << clog;
+}
+// zstd_compress.c:1427-1555 ZSTD_dictAndWindowLog + ZSTD_adjustCParams_internal (strategies below btlazy2: cycleLog == chainLog;
+// the row finder's hashLog cap, 24 + rowLog, is out of reach of these rows)
 ZSA_HD ZsaCParams zsa_adjustCParams(ZsaCParams cp, u64 srcSize, u64 dictSize, int mode)
 {
     if (mode == zsa_cpm_createCDict) { if (dictSize && srcSize == ZSA_SIZE_UNKNOWN) srcSize = 513; }
@@ -62,9 +88,9 @@ ZSA_HD int zsa_resolveCParams(ZsaCParams* out, int level, u64 srcSizeHint, u64 d
     }
     u32 const tableID = (rSize <= 256 * 1024) + (rSize <= 128 * 1024) + (rSize <= 16 * 1024);
     u32 row;
-    if (level == 0) row = 3; else if (level < 0) row = 0; else if (level > 4) return 1; else row = (u32)level;
+    if (level == 0) row = 3; else if (level < 0) row = 0; else if (level > ZSA_MAX_LEVEL) return 1; else row = (u32)level;
     ZsaCParams cp = zsa_levelRow(tableID, row);
-    if (cp.strat == 0) return 1;
+    if (cp.strat > 5) return 1;
     if (level < 0) { int const minLevel = -(1 << 17); int const cl = level < minLevel ? minLevel : level; cp.tlen = (u32)(-cl); }
     *out = zsa_adjustCParams(cp, srcSizeHint, dictSize, mode);
     return 0;
