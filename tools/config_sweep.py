@@ -47,6 +47,11 @@ def run(name, kind, fs, n, seed, level, dictionary=None, steps=3):
 
 g = json.load(open(os.path.join(ROOT, "tests", "golden", "dict_cases.json")))
 trained = base64.b64decode(g["dicts"]["trained_json_8k"]["b64"])
+if len(sys.argv) > 1 and sys.argv[1] == "lazy":   # the greedy / lazy rows only
+    run("   128 KiB log frames, level 5 (greedy, row hash)", "log", 131072, 8192, 42, 5, steps=2)
+    run("   16 KiB log frames, level 5 (lazy, hash chain)", "log", 16384, 65536, 45, 5, steps=2)
+    run("   128 KiB log frames, level 7 (lazy2, row hash)", "log", 131072, 8192, 42, 7, steps=2)
+    sys.exit(0)
 run("C1 64 KiB JSON blocks, level 1", "json", 65536, 16384, 1234, 1)
 run("C2 128 KiB log frames, level 1 (bench.py)", "log", 131072, 8192, 42, 1)
 run("C3 1 KiB JSON payloads + trained dictionary", "json", 1024, 1 << 20, 7, 1, dictionary=trained)

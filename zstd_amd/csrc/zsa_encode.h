@@ -1727,12 +1727,8 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
                 wv_sync();
                 u32 rep[3] = { S->prevRep[0], S->prevRep[1], S->prevRep[2] };
                 u32 lastLL = 0, nbSeq;
-                if (P.strat >= 3) {   // greedy / lazy / lazy2 (never with a dictionary here): serial for now, zsa_lazy.h
-                    nbSeq = 0;
-                    u32 ntu = LZ.nextToUpdate;
-                    if (lane == 0) { nbSeq = zsa_parse_lazy(LZ, Wn.dictLimit, ip, blockSize, P.strat - 3, rep, W.seq, &lastLL); ntu = LZ.nextToUpdate; }
-                    nbSeq = wv_shfl(nbSeq, 0); lastLL = wv_shfl(lastLL, 0); LZ.nextToUpdate = wv_shfl(ntu, 0);
-                    rep[0] = wv_shfl(rep[0], 0); rep[1] = wv_shfl(rep[1], 0);
+                if (P.strat >= 3) {   // greedy / lazy / lazy2 (never with a dictionary here): wave-uniform, zsa_lazy.h
+                    nbSeq = zsa_parse_lazy(LZ, Wn.dictLimit, ip, blockSize, P.strat - 3, rep, W.seq, &lastLL, lane);
                 } else if (P.strat == 2) {   // ZSTD_dfast (never with a dictionary here): serial for now, zsa_dfast.h
                     nbSeq = 0;
                     if (lane == 0) nbSeq = zsa_parse_dfast(hashTable, hashTable + (1u << P.hlog), P, Wn.base, Wn.dictLimit, ip, blockSize, rep, W.seq, &lastLL);

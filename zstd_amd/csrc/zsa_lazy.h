@@ -6,7 +6,13 @@
 // Tables, all in the workgroup's global scratch: hashTable (1 << hashLog cells), then either the chain table
 // (1 << chainLog cells) or the row finder's tag table (1 << hashLog bytes; byte 0 of every row is the row's head).
 //
-// First version: the chain is walked by one lane (the frames of a launch still run 16 per CU), like zsa_dfast.h.  Two
+// The parser runs in wave-uniform control flow: every lane follows the same chain with the same values (loads of one
+// address by all lanes are one transaction) and lane 0 alone stores, so that the one step with real parallelism can use
+// the whole wave -- entering the positions a match skipped over into the row table (zsa_row_update, 64 positions per
+// round trip instead of one).  The search itself is still one candidate after the other.  Wherever lane 0 stores into a
+// table that all lanes read, a wave fence sits between the reads and the store and another one behind the store: free
+// on the GPU (the lanes move in lock step anyway), and the rendezvous that keeps the lanes of the CPU emulator
+// (tests/emu, which runs the lanes one after the other between rendezvous) seeing the same table.  Two
 // things of the reference are not restated because they cannot change a result (argued in oracle/zo_lazy.inc, which is
 // pinned to the reference build): the row finder's 8-entry hash cache -- hashes are taken at the point of use; its one
 // visible effect, the parser stopping 8 bytes earlier, is kept -- and the SIMD forms of the tag comparison, replaced by a
@@ -45,15 +51,17 @@ struct ZsaLazyCtx {
 
 // ---------------------------------------------------------------- hash chain
 // zstd_lazy.c:621-646 ZSTD_insertAndFindFirstIndex_internal
-ZSA_DEV u32 zsa_hc_insertAndFind(ZsaLazyCtx& C, const u8* ip, u64 vip)
+ZSA_DEV u32 zsa_hc_insertAndFind(ZsaLazyCtx& C, const u8* ip, u64 vip, int lane)
 {
     u32 const chainMask = (1u << C.clog) - 1u;
     u32 const target = (u32)(ip - C.base);
     u32 idx = C.nextToUpdate;
     while (idx < target) {
         u32 const h = zsa_hash(wv_ldg64(C.base + idx), C.hlog, C.mls);
-        wv_stg_cell(C.chainTable + (idx & chainMask), wv_ldg_cell(C.hashTable + h));
-        wv_stg_cell(C.hashTable + h, idx);
+        u32 const prev = wv_ldg_cell(C.hashTable + h);
+        wv_lds_fence();
+        if (lane == 0) { wv_stg_cell(C.chainTable + (idx & chainMask), prev); wv_stg_cell(C.hashTable + h, idx); }
+        wv_lds_fence();
         idx++;
         if (C.lazySkipping) break;
     }
@@ -61,7 +69,7 @@ ZSA_DEV u32 zsa_hc_insertAndFind(ZsaLazyCtx& C, const u8* ip, u64 vip)
     return wv_ldg_cell(C.hashTable + zsa_hash(vip, C.hlog, C.mls));
 }
 // zstd_lazy.c:655-761 ZSTD_HcFindBestMatch, noDict.  Returns the best length (3 = none), offBase in *offBasePtr.
-ZSA_DEV u32 zsa_hc_findBestMatch(ZsaLazyCtx& C, const u8* ip, const u8* iLimit, u32* offBasePtr)
+ZSA_DEV u32 zsa_hc_findBestMatch(ZsaLazyCtx& C, const u8* ip, const u8* iLimit, u32* offBasePtr, int lane)
 {
     u32 const chainSize = 1u << C.clog, chainMask = chainSize - 1u;
     u32 const curr = (u32)(ip - C.base);
@@ -71,7 +79,7 @@ ZSA_DEV u32 zsa_hc_findBestMatch(ZsaLazyCtx& C, const u8* ip, const u8* iLimit, 
     u32 nbAttempts = 1u << C.slog;
     u32 ml = 4 - 1;
     u64 const vip = wv_ldg64(ip);
-    u32 matchIndex = zsa_hc_insertAndFind(C, ip, vip);
+    u32 matchIndex = zsa_hc_insertAndFind(C, ip, vip, lane);
     for (; (matchIndex >= lowLimit) & (nbAttempts > 0); nbAttempts--) {
         u32 currentMl = 0;
         const u8* const match = C.base + matchIndex;
@@ -90,36 +98,57 @@ ZSA_DEV u32 zsa_hc_findBestMatch(ZsaLazyCtx& C, const u8* ip, const u8* iLimit, 
 }
 
 // ---------------------------------------------------------------- row hash
-// zstd_lazy.c:786-791 ZSTD_row_nextIndex + :867-890 one position of ZSTD_row_update_internalImpl
-ZSA_DEV void zsa_row_put(ZsaLazyCtx& C, u32 relRow, u32 tag, u32 idx, u32 rowMask)
+// zstd_lazy.c:786-791 ZSTD_row_nextIndex + :1224-1230: one position enters its row (uniform; lane 0 stores)
+ZSA_DEV void zsa_row_put(ZsaLazyCtx& C, u32 relRow, u32 tag, u32 idx, u32 rowMask, u32 head, int lane)
 {
     u8* const tagRow = C.tagTable + relRow;
-    u32 next = (wv_ldg8(tagRow) - 1u) & rowMask;
+    u32 next = (head - 1u) & rowMask;
     next += (next == 0) ? rowMask : 0;
-    wv_stg8(tagRow, next);
-    wv_stg8(tagRow + next, tag);
-    wv_stg_cell(C.hashTable + relRow + next, idx);
+    if (lane == 0) { wv_stg8(tagRow, next); wv_stg8(tagRow + next, tag); wv_stg_cell(C.hashTable + relRow + next, idx); }
 }
-ZSA_DEV void zsa_row_insert(ZsaLazyCtx& C, u32 idx, u32 rowMask)
+// zstd_lazy.c:867-890 ZSTD_row_update_internalImpl for positions [from, to), 64 per step: lane k takes position
+// from + k.  The reference enters them one after the other; the only coupling between two of them is the head of a row
+// both fall into, which cycles through the slots rowMask, rowMask-1, .., 1.  So the r-th position (in order) of this step
+// that falls into a row takes the slot r steps behind the row's head, and the last one leaves the head there; a position
+// whose slot a later position of the same step takes again (rowEntries-1 or more later ones in its row: runs of equal
+// bytes) is not stored at all, which is what overwriting would have left.
+ZSA_DEV void zsa_row_insert_range(ZsaLazyCtx& C, u32 from, u32 to, u32 rowMask, int lane)
 {
-    u32 const hash = zsa_hash_salted(wv_ldg64(C.base + idx), C.rowHashLog + 8, C.mls, ZSA_FRESH_HASH_SALT);
-    zsa_row_put(C, (hash >> 8) << C.rowLog, hash & 0xFF, idx, rowMask);
+    for (u32 b = from; b < to; b += ZSA_WAVE) {
+        u32 const n = (to - b) < ZSA_WAVE ? (to - b) : ZSA_WAVE;
+        bool const act = (u32)lane < n;
+        u32 const pos = b + (act ? (u32)lane : 0u);
+        u32 const hash = zsa_hash_salted(wv_ldg64(C.base + pos), C.rowHashLog + 8, C.mls, ZSA_FRESH_HASH_SALT);
+        u32 const relRow = (hash >> 8) << C.rowLog;
+        u8* const tagRow = C.tagTable + relRow;
+        u32 const head0 = wv_ldg8(tagRow) & rowMask;
+        u32 rank = 0, count = 0;   // positions of this step in my row: before me / in total
+        for (u32 s2 = 0; s2 < n; s2++) {
+            bool const same = wv_readlane(relRow, (int)s2) == relRow;
+            rank += (same && s2 < (u32)lane);
+            count += same;
+        }
+        u32 const c0 = (head0 ? head0 : 1u) - 1u;                       // head 0 (fresh row) steps to rowMask like head 1
+        u32 const slot = ((c0 + 5u * rowMask - (rank + 1u)) % rowMask) + 1u;   // rank + 1 <= 64 <= 5 * rowMask
+        if (act && (count - 1u - rank) < rowMask) { wv_stg8(tagRow + slot, hash & 0xFF); wv_stg_cell(C.hashTable + relRow + slot, pos); }
+        if (act && rank == count - 1u) wv_stg8(tagRow, slot);
+        wv_sync();   // the next step, and the search that follows, read what this one stored
+    }
 }
 // zstd_lazy.c:896-923 ZSTD_row_update_internal (useCache == 1): long gaps are indexed at their two ends only
-ZSA_DEV void zsa_row_update(ZsaLazyCtx& C, const u8* ip, u32 rowMask)
+ZSA_DEV void zsa_row_update(ZsaLazyCtx& C, const u8* ip, u32 rowMask, int lane)
 {
     u32 idx = C.nextToUpdate;
     u32 const target = (u32)(ip - C.base);
     if (target - idx > 384) {
-        u32 const bound = idx + 96;
-        for (; idx < bound; idx++) zsa_row_insert(C, idx, rowMask);
+        zsa_row_insert_range(C, idx, idx + 96, rowMask, lane);
         idx = target - 32;
     }
-    for (; idx < target; idx++) zsa_row_insert(C, idx, rowMask);
+    zsa_row_insert_range(C, idx, target, rowMask, lane);
     C.nextToUpdate = target;
 }
 // zstd_lazy.c:1120-1313 ZSTD_RowFindBestMatch, noDict
-ZSA_DEV u32 zsa_row_findBestMatch(ZsaLazyCtx& C, const u8* ip, const u8* iLimit, u32* offBasePtr)
+ZSA_DEV u32 zsa_row_findBestMatch(ZsaLazyCtx& C, const u8* ip, const u8* iLimit, u32* offBasePtr, int lane)
 {
     u32 const curr = (u32)(ip - C.base);
     u32 const maxDistance = 1u << C.wlog;
@@ -130,7 +159,7 @@ ZSA_DEV u32 zsa_row_findBestMatch(ZsaLazyCtx& C, const u8* ip, const u8* iLimit,
     u32 matchBuffer[64];
     u32 numMatches = 0;
 
-    if (!C.lazySkipping) zsa_row_update(C, ip, rowMask);   // :1184-1186
+    if (!C.lazySkipping) zsa_row_update(C, ip, rowMask, lane);   // :1184-1186
     else C.nextToUpdate = curr;                            // :1187-1193
     u64 const vip = wv_ldg64(ip);
     u32 const hash = zsa_hash_salted(vip, C.rowHashLog + 8, C.mls, ZSA_FRESH_HASH_SALT);
@@ -140,12 +169,12 @@ ZSA_DEV u32 zsa_row_findBestMatch(ZsaLazyCtx& C, const u8* ip, const u8* iLimit,
     u8* const tagRow = C.tagTable + relRow;
     // :1040-1102 the match mask: bit p set iff tagRow[p] == tag (rows are rowEntries-aligned; all loads in one round trip)
     u64 eq = 0;
-    u32 head = 0;
+    u32 head = 0, headByte = 0;
     {   u64 const splat = (u64)tag * 0x0101010101010101ULL;
         u32 const nW = rowEntries >> 3;
         for (u32 w = 0; w < nW; w++) {
             u64 const t = wv_ldg64(tagRow + 8u * w);
-            if (w == 0) head = (u32)t & rowMask;
+            if (w == 0) { headByte = (u32)t & 0xFF; head = headByte & rowMask; }
             u64 const x = t ^ splat;                                                    // zero bytes are the equal ones
             u64 const nz = (((x & 0x7F7F7F7F7F7F7F7FULL) + 0x7F7F7F7F7F7F7F7FULL) | x) & 0x8080808080808080ULL;
             u64 const z = (nz ^ 0x8080808080808080ULL) >> 7;                            // 0x01 in every equal byte
@@ -164,7 +193,9 @@ ZSA_DEV u32 zsa_row_findBestMatch(ZsaLazyCtx& C, const u8* ip, const u8* iLimit,
             --nbAttempts;
         }
     }
-    zsa_row_put(C, relRow, tag, C.nextToUpdate++, rowMask);   // :1224-1230 the current position enters the row right away
+    wv_lds_fence();
+    zsa_row_put(C, relRow, tag, C.nextToUpdate++, rowMask, headByte, lane);   // :1224-1230 the current position enters the row right away
+    wv_lds_fence();
     for (u32 k = 0; k < numMatches; ++k) {                   // :1232-1258
         u32 const matchIndex = matchBuffer[k];
         u32 currentMl = 0;
@@ -180,17 +211,17 @@ ZSA_DEV u32 zsa_row_findBestMatch(ZsaLazyCtx& C, const u8* ip, const u8* iLimit,
     return ml;
 }
 
-ZSA_DEV u32 zsa_searchMax(ZsaLazyCtx& C, const u8* ip, const u8* iend, u32* offBasePtr)
+ZSA_DEV u32 zsa_searchMax(ZsaLazyCtx& C, const u8* ip, const u8* iend, u32* offBasePtr, int lane)
 {   // zstd_lazy.c:1466-1487
-    return C.useRow ? zsa_row_findBestMatch(C, ip, iend, offBasePtr) : zsa_hc_findBestMatch(C, ip, iend, offBasePtr);
+    return C.useRow ? zsa_row_findBestMatch(C, ip, iend, offBasePtr, lane) : zsa_hc_findBestMatch(C, ip, iend, offBasePtr, lane);
 }
 
 // depth 0 = greedy, 1 = lazy, 2 = lazy2 (zstd_lazy.c:1493-1757).  Appends packed sequences to seqOut, returns their
-// number; rep[] and *lastLL are updated.  Runs on one lane.
-ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcSize, u32 depth, u32 rep[3], u64* seqOut, u32* lastLL)
+// number; rep[] and *lastLL are updated.  Called by all lanes with uniform arguments; everything it computes is uniform.
+ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcSize, u32 depth, u32 rep[3], u64* seqOut, u32* lastLL, int lane)
 {
     const u8* const istart = src;
-    const u8* ip = istart + wv_vzero();   // per-lane state (zsa_wave_hip.h)
+    const u8* ip = istart;
     const u8* anchor = istart;
     const u8* const iend = istart + srcSize;
     s32 const margin = C.useRow ? 8 + 8 : 8;             // :1505 (the row finder's hash cache looks 8 positions ahead)
@@ -223,7 +254,7 @@ ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcS
         }
         if (!storeNow) {
             {   u32 offbaseFound = 999999999;   // :1585-1589
-                u32 const ml2 = zsa_searchMax(C, ip, iend, &offbaseFound);
+                u32 const ml2 = zsa_searchMax(C, ip, iend, &offbaseFound, lane);
                 if (ml2 > matchLength) { matchLength = ml2; start = ip; offBase = offbaseFound; }
             }
             if (matchLength < 4) {   // :1591-1603
@@ -242,7 +273,7 @@ ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcS
                     if ((mlRep >= 4) && (gain2 > gain1)) { matchLength = mlRep; offBase = 1; start = ip; }
                 }
                 {   u32 ofbCandidate = 999999999;
-                    u32 const ml2 = zsa_searchMax(C, ip, iend, &ofbCandidate);
+                    u32 const ml2 = zsa_searchMax(C, ip, iend, &ofbCandidate, lane);
                     s32 const gain2 = (s32)(ml2 * 4 - ZSA_HB(ofbCandidate));
                     s32 const gain1 = (s32)(matchLength * 4 - ZSA_HB(offBase) + 4);
                     if ((ml2 >= 4) && (gain2 > gain1)) { matchLength = ml2; offBase = ofbCandidate; start = ip; continue; }
@@ -256,7 +287,7 @@ ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcS
                         if ((mlRep >= 4) && (gain2 > gain1)) { matchLength = mlRep; offBase = 1; start = ip; }
                     }
                     {   u32 ofbCandidate = 999999999;
-                        u32 const ml2 = zsa_searchMax(C, ip, iend, &ofbCandidate);
+                        u32 const ml2 = zsa_searchMax(C, ip, iend, &ofbCandidate, lane);
                         s32 const gain2 = (s32)(ml2 * 4 - ZSA_HB(ofbCandidate));
                         s32 const gain1 = (s32)(matchLength * 4 - ZSA_HB(offBase) + 7);
                         if ((ml2 >= 4) && (gain2 > gain1)) { matchLength = ml2; offBase = ofbCandidate; start = ip; continue; }
@@ -271,14 +302,16 @@ ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcS
             }
         }
         // :1700-1704 _storeSequence
-        seqOut[nbSeq++] = zsa_packseq((u32)(start - anchor), matchLength - ZSA_MINMATCH, offBase);
+        if (lane == 0) seqOut[nbSeq] = zsa_packseq((u32)(start - anchor), matchLength - ZSA_MINMATCH, offBase);
+        nbSeq++;
         anchor = ip = start + matchLength;
         C.lazySkipping = 0;   // :1705-1711
         // :1735-1745 immediate repcode
         while ((ZSA_UPTO_LIMIT(ip) & (offset_2 > 0)) && (wv_ldg32(ip) == wv_ldg32(ip - offset_2))) {
             matchLength = zsa_dfast_count(ip + 4, ip + 4 - offset_2, iend) + 4;
             { u32 const t = offset_2; offset_2 = offset_1; offset_1 = t; }
-            seqOut[nbSeq++] = zsa_packseq(0, matchLength - ZSA_MINMATCH, 1);
+            if (lane == 0) seqOut[nbSeq] = zsa_packseq(0, matchLength - ZSA_MINMATCH, 1);
+            nbSeq++;
             ip += matchLength;
             anchor = ip;
         }
