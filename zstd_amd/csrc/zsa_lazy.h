@@ -9,7 +9,8 @@
 // The parser runs in wave-uniform control flow: every lane follows the same chain with the same values (loads of one
 // address by all lanes are one transaction) and lane 0 alone stores, so that the one step with real parallelism can use
 // the whole wave -- entering the positions a match skipped over into the row table (zsa_row_update, 64 positions per
-// round trip instead of one).  The search itself is still one candidate after the other.  Wherever lane 0 stores into a
+// round trip instead of one), likewise for the hash chain, and measuring the candidates of a search (one per lane).
+// Wherever lane 0 stores into a
 // table that all lanes read, a wave fence sits between the reads and the store and another one behind the store: free
 // on the GPU (the lanes move in lock step anyway), and the rendezvous that keeps the lanes of the CPU emulator
 // (tests/emu, which runs the lanes one after the other between rendezvous) seeing the same table.  Two
@@ -49,26 +50,56 @@ struct ZsaLazyCtx {
     bool useRow;
 };
 
+// ---------------------------------------------------------------- candidate evaluation, one candidate per lane
+// Both finders walk their candidates in a fixed order and keep the first one that is strictly longer than everything
+// before it (zstd_lazy.c:696-720, :1232-1258).  The reference skips the full comparison of a candidate whose 4 bytes
+// at [ml-3, ml+1) differ -- such a candidate cannot be longer than ml, so measuring every candidate in full and taking
+// the first maximum is the same selection; its early exit when a match reaches the end of the input changes nothing
+// either (nothing can be longer).  Lane k measures candidate k; `ml` and *offBasePtr are updated like the loop would.
+ZSA_DEV void zsa_lazy_evaluate(const ZsaLazyCtx& C, const u8* ip, const u8* iLimit, u32 curr, u32 myIndex, u32 nCand,
+                               u32* ml, u32* offBasePtr, int lane)
+{
+    bool const mine = (u32)lane < nCand;
+    u32 const len = mine ? zsa_dfast_count(ip, C.base + myIndex, iLimit) : 0u;
+    u32 const best = wv_reduce_max(len);
+    if (best > *ml) {
+        int const which = __builtin_ctzll(wv_ballot(mine && len == best));
+        *ml = best;
+        *offBasePtr = (curr - wv_readlane(myIndex, which)) + 3;
+    }
+}
+
 // ---------------------------------------------------------------- hash chain
-// zstd_lazy.c:621-646 ZSTD_insertAndFindFirstIndex_internal
+// zstd_lazy.c:621-646 ZSTD_insertAndFindFirstIndex_internal: positions [nextToUpdate, target) enter the chain, 64 per
+// step (lane k takes position b + k).  A position's predecessor is the cell's old content, or the nearest earlier
+// position of the same step with the same hash; the last position per hash of a step is what the cell holds afterwards.
 ZSA_DEV u32 zsa_hc_insertAndFind(ZsaLazyCtx& C, const u8* ip, u64 vip, int lane)
 {
     u32 const chainMask = (1u << C.clog) - 1u;
     u32 const target = (u32)(ip - C.base);
-    u32 idx = C.nextToUpdate;
-    while (idx < target) {
-        u32 const h = zsa_hash(wv_ldg64(C.base + idx), C.hlog, C.mls);
-        u32 const prev = wv_ldg_cell(C.hashTable + h);
-        wv_lds_fence();
-        if (lane == 0) { wv_stg_cell(C.chainTable + (idx & chainMask), prev); wv_stg_cell(C.hashTable + h, idx); }
-        wv_lds_fence();
-        idx++;
-        if (C.lazySkipping) break;
+    u32 const from = C.nextToUpdate;
+    u32 const to = (C.lazySkipping && from < target) ? from + 1 : target;   // :639-641 one position only while skipping
+    for (u32 b = from; b < to; b += ZSA_WAVE) {
+        u32 const n = (to - b) < ZSA_WAVE ? (to - b) : ZSA_WAVE;
+        bool const act = (u32)lane < n;
+        u32 const pos = b + (act ? (u32)lane : 0u);
+        u32 const h = zsa_hash(wv_ldg64(C.base + pos), C.hlog, C.mls);
+        u32 prev = wv_ldg_cell(C.hashTable + h);
+        bool last = true;
+        for (u32 s2 = 0; s2 < n; s2++) {
+            bool const same = wv_readlane(h, (int)s2) == h;
+            if (same && s2 < (u32)lane) prev = b + s2;
+            if (same && s2 > (u32)lane) last = false;
+        }
+        if (act) wv_stg_cell(C.chainTable + (pos & chainMask), prev);
+        if (act && last) wv_stg_cell(C.hashTable + h, pos);
+        wv_sync();   // the next step and the search read what this one stored
     }
     C.nextToUpdate = target;
     return wv_ldg_cell(C.hashTable + zsa_hash(vip, C.hlog, C.mls));
 }
 // zstd_lazy.c:655-761 ZSTD_HcFindBestMatch, noDict.  Returns the best length (3 = none), offBase in *offBasePtr.
+// The chain is walked first (its course depends on indices only), 64 candidates at a time, then measured by all lanes.
 ZSA_DEV u32 zsa_hc_findBestMatch(ZsaLazyCtx& C, const u8* ip, const u8* iLimit, u32* offBasePtr, int lane)
 {
     u32 const chainSize = 1u << C.clog, chainMask = chainSize - 1u;
@@ -80,19 +111,18 @@ ZSA_DEV u32 zsa_hc_findBestMatch(ZsaLazyCtx& C, const u8* ip, const u8* iLimit, 
     u32 ml = 4 - 1;
     u64 const vip = wv_ldg64(ip);
     u32 matchIndex = zsa_hc_insertAndFind(C, ip, vip, lane);
-    for (; (matchIndex >= lowLimit) & (nbAttempts > 0); nbAttempts--) {
-        u32 currentMl = 0;
-        const u8* const match = C.base + matchIndex;
-        u32 const next = wv_ldg_cell(C.chainTable + (matchIndex & chainMask));   // rides along with the byte check
-        u32 const mine = ml == 3 ? (u32)vip : wv_ldg32(ip + ml - 3);
-        if (wv_ldg32(match + ml - 3) == mine) currentMl = zsa_dfast_count(ip, match, iLimit);
-        if (currentMl > ml) {
-            ml = currentMl;
-            *offBasePtr = (curr - matchIndex) + 3;
-            if (ip + currentMl == iLimit) break;
+    bool more = (matchIndex >= lowLimit) & (nbAttempts > 0);
+    while (more) {
+        u32 myIndex = 0, nCand = 0;
+        while (more && nCand < ZSA_WAVE) {
+            if ((u32)lane == nCand) myIndex = matchIndex;
+            nCand++; nbAttempts--;
+            if (matchIndex <= minChain) { more = false; break; }
+            matchIndex = wv_ldg_cell(C.chainTable + (matchIndex & chainMask));
+            more = (matchIndex >= lowLimit) & (nbAttempts > 0);
         }
-        if (matchIndex <= minChain) break;
-        matchIndex = next;
+        zsa_lazy_evaluate(C, ip, iLimit, curr, myIndex, nCand, &ml, offBasePtr, lane);
+        if (ip + ml == iLimit) break;   // :715 best possible
     }
     return ml;
 }
@@ -156,8 +186,6 @@ ZSA_DEV u32 zsa_row_findBestMatch(ZsaLazyCtx& C, const u8* ip, const u8* iLimit,
     u32 const rowEntries = 1u << C.rowLog, rowMask = rowEntries - 1u;
     u32 nbAttempts = 1u << (C.slog < C.rowLog ? C.slog : C.rowLog);
     u32 ml = 4 - 1;
-    u32 matchBuffer[64];
-    u32 numMatches = 0;
 
     if (!C.lazySkipping) zsa_row_update(C, ip, rowMask, lane);   // :1184-1186
     else C.nextToUpdate = curr;                            // :1187-1193
@@ -181,33 +209,25 @@ ZSA_DEV u32 zsa_row_findBestMatch(ZsaLazyCtx& C, const u8* ip, const u8* iLimit,
             eq |= ((z * 0x0102040810204080ULL) >> 56) << (8u * w);
         }
     }
-    // :1205-1222: candidates from the newest (head) to the oldest; position 0 holds the head byte, not an entry
+    // :1205-1222: candidates from the newest (head) to the oldest; position 0 holds the head byte, not an entry.  Lane k
+    // takes the k-th of them: all row cells are read in one round trip, the list ends before the first index below lowLimit.
+    u32 myIndex = 0, nCand = 0;
     {   u64 rot = head ? ((eq >> head) | (eq << (rowEntries - head))) : eq;
         if (rowEntries < 64) rot &= (((u64)1 << rowEntries) - 1u);
-        for (; rot && nbAttempts > 0; rot &= rot - 1) {
-            u32 const matchPos = (head + (u32)__builtin_ctzll(rot)) & rowMask;
-            if (matchPos == 0) continue;
-            u32 const matchIndex = wv_ldg_cell(row + matchPos);
-            if (matchIndex < lowLimit) break;
-            matchBuffer[numMatches++] = matchIndex;
-            --nbAttempts;
+        rot &= ~((u64)1 << ((rowEntries - head) & rowMask));           // the bit of position 0
+        u32 myPos = 0;
+        for (; rot && nCand < nbAttempts; rot &= rot - 1) {
+            if ((u32)lane == nCand) myPos = (head + (u32)__builtin_ctzll(rot)) & rowMask;
+            nCand++;
         }
+        myIndex = wv_ldg_cell(row + myPos);
+        u64 const low = wv_ballot((u32)lane < nCand && myIndex < lowLimit);
+        if (low) nCand = (u32)__builtin_ctzll(low);
     }
     wv_lds_fence();
     zsa_row_put(C, relRow, tag, C.nextToUpdate++, rowMask, headByte, lane);   // :1224-1230 the current position enters the row right away
     wv_lds_fence();
-    for (u32 k = 0; k < numMatches; ++k) {                   // :1232-1258
-        u32 const matchIndex = matchBuffer[k];
-        u32 currentMl = 0;
-        const u8* const match = C.base + matchIndex;
-        u32 const mine = ml == 3 ? (u32)vip : wv_ldg32(ip + ml - 3);
-        if (wv_ldg32(match + ml - 3) == mine) currentMl = zsa_dfast_count(ip, match, iLimit);
-        if (currentMl > ml) {
-            ml = currentMl;
-            *offBasePtr = (curr - matchIndex) + 3;
-            if (ip + currentMl == iLimit) break;
-        }
-    }
+    zsa_lazy_evaluate(C, ip, iLimit, curr, myIndex, nCand, &ml, offBasePtr, lane);   // :1232-1258
     return ml;
 }
 
