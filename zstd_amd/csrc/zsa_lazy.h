@@ -41,6 +41,7 @@ ZSA_DEV u32 zsa_hash_salted(u64 v, u32 hBits, u32 mls, u64 salt)
 }
 
 struct ZsaLazyCtx {
+    ZsaEncShared* S;         // phase accounting only (ZSA_PARSE_PROF builds)
     u32* hashTable; u32* chainTable; u8* tagTable;
     const u8* base;
     u32 hlog, clog, wlog, slog, mls, rowLog, rowHashLog;
@@ -100,7 +101,7 @@ ZSA_DEV u32 zsa_hc_insertAndFind(ZsaLazyCtx& C, const u8* ip, u64 vip, int lane)
 }
 // zstd_lazy.c:655-761 ZSTD_HcFindBestMatch, noDict.  Returns the best length (3 = none), offBase in *offBasePtr.
 // The chain is walked first (its course depends on indices only), 64 candidates at a time, then measured by all lanes.
-ZSA_DEV u32 zsa_hc_findBestMatch(ZsaLazyCtx& C, const u8* ip, const u8* iLimit, u32* offBasePtr, int lane)
+ZSA_DEV u32 zsa_hc_findBestMatch(ZsaLazyCtx& C, const u8* ip, u64 vip, const u8* iLimit, u32* offBasePtr, int lane)
 {
     u32 const chainSize = 1u << C.clog, chainMask = chainSize - 1u;
     u32 const curr = (u32)(ip - C.base);
@@ -109,7 +110,6 @@ ZSA_DEV u32 zsa_hc_findBestMatch(ZsaLazyCtx& C, const u8* ip, const u8* iLimit, 
     u32 const minChain = curr > chainSize ? curr - chainSize : 0;
     u32 nbAttempts = 1u << C.slog;
     u32 ml = 4 - 1;
-    u64 const vip = wv_ldg64(ip);
     u32 matchIndex = zsa_hc_insertAndFind(C, ip, vip, lane);
     bool more = (matchIndex >= lowLimit) & (nbAttempts > 0);
     while (more) {
@@ -178,7 +178,7 @@ ZSA_DEV void zsa_row_update(ZsaLazyCtx& C, const u8* ip, u32 rowMask, int lane)
     C.nextToUpdate = target;
 }
 // zstd_lazy.c:1120-1313 ZSTD_RowFindBestMatch, noDict
-ZSA_DEV u32 zsa_row_findBestMatch(ZsaLazyCtx& C, const u8* ip, const u8* iLimit, u32* offBasePtr, int lane)
+ZSA_DEV u32 zsa_row_findBestMatch(ZsaLazyCtx& C, const u8* ip, u64 vip, const u8* iLimit, u32* offBasePtr, int lane)
 {
     u32 const curr = (u32)(ip - C.base);
     u32 const maxDistance = 1u << C.wlog;
@@ -187,30 +187,22 @@ ZSA_DEV u32 zsa_row_findBestMatch(ZsaLazyCtx& C, const u8* ip, const u8* iLimit,
     u32 nbAttempts = 1u << (C.slog < C.rowLog ? C.slog : C.rowLog);
     u32 ml = 4 - 1;
 
+    ZSA_PPROF(C.S, lane, 1);
     if (!C.lazySkipping) zsa_row_update(C, ip, rowMask, lane);   // :1184-1186
     else C.nextToUpdate = curr;                            // :1187-1193
-    u64 const vip = wv_ldg64(ip);
+    ZSA_PPROF(C.S, lane, 8);
     u32 const hash = zsa_hash_salted(vip, C.rowHashLog + 8, C.mls, ZSA_FRESH_HASH_SALT);
     u32 const relRow = (hash >> 8) << C.rowLog;
     u32 const tag = hash & 0xFF;
-    u32* const row = C.hashTable + relRow;
-    u8* const tagRow = C.tagTable + relRow;
-    // :1040-1102 the match mask: bit p set iff tagRow[p] == tag (rows are rowEntries-aligned; all loads in one round trip)
-    u64 eq = 0;
-    u32 head = 0, headByte = 0;
-    {   u64 const splat = (u64)tag * 0x0101010101010101ULL;
-        u32 const nW = rowEntries >> 3;
-        for (u32 w = 0; w < nW; w++) {
-            u64 const t = wv_ldg64(tagRow + 8u * w);
-            if (w == 0) { headByte = (u32)t & 0xFF; head = headByte & rowMask; }
-            u64 const x = t ^ splat;                                                    // zero bytes are the equal ones
-            u64 const nz = (((x & 0x7F7F7F7F7F7F7F7FULL) + 0x7F7F7F7F7F7F7F7FULL) | x) & 0x8080808080808080ULL;
-            u64 const z = (nz ^ 0x8080808080808080ULL) >> 7;                            // 0x01 in every equal byte
-            eq |= ((z * 0x0102040810204080ULL) >> 56) << (8u * w);
-        }
-    }
+    // :1040-1102 the match mask and the row's cells in one round trip: lane p reads tag byte p and cell p of the row
+    // (rowEntries <= 64), so "bit p set iff tagRow[p] == tag" is one ballot
+    bool const inRow = (u32)lane < rowEntries;
+    u32 const myTag = wv_ldg8(C.tagTable + relRow + (inRow ? (u32)lane : 0u));
+    u32 const myCell = wv_ldg_cell(C.hashTable + relRow + (inRow ? (u32)lane : 0u));
+    u64 const eq = wv_ballot(inRow && myTag == tag);
+    u32 const headByte = wv_readlane(myTag, 0), head = headByte & rowMask;
     // :1205-1222: candidates from the newest (head) to the oldest; position 0 holds the head byte, not an entry.  Lane k
-    // takes the k-th of them: all row cells are read in one round trip, the list ends before the first index below lowLimit.
+    // takes the k-th of them; the list ends before the first index below lowLimit.
     u32 myIndex = 0, nCand = 0;
     {   u64 rot = head ? ((eq >> head) | (eq << (rowEntries - head))) : eq;
         if (rowEntries < 64) rot &= (((u64)1 << rowEntries) - 1u);
@@ -220,20 +212,22 @@ ZSA_DEV u32 zsa_row_findBestMatch(ZsaLazyCtx& C, const u8* ip, const u8* iLimit,
             if ((u32)lane == nCand) myPos = (head + (u32)__builtin_ctzll(rot)) & rowMask;
             nCand++;
         }
-        myIndex = wv_ldg_cell(row + myPos);
+        myIndex = wv_shfl(myCell, (int)myPos);
         u64 const low = wv_ballot((u32)lane < nCand && myIndex < lowLimit);
         if (low) nCand = (u32)__builtin_ctzll(low);
     }
     wv_lds_fence();
     zsa_row_put(C, relRow, tag, C.nextToUpdate++, rowMask, headByte, lane);   // :1224-1230 the current position enters the row right away
     wv_lds_fence();
+    ZSA_PPROF(C.S, lane, 9);
     zsa_lazy_evaluate(C, ip, iLimit, curr, myIndex, nCand, &ml, offBasePtr, lane);   // :1232-1258
+    ZSA_PPROF(C.S, lane, 10);
     return ml;
 }
 
-ZSA_DEV u32 zsa_searchMax(ZsaLazyCtx& C, const u8* ip, const u8* iend, u32* offBasePtr, int lane)
-{   // zstd_lazy.c:1466-1487
-    return C.useRow ? zsa_row_findBestMatch(C, ip, iend, offBasePtr, lane) : zsa_hc_findBestMatch(C, ip, iend, offBasePtr, lane);
+ZSA_DEV u32 zsa_searchMax(ZsaLazyCtx& C, const u8* ip, u64 vip, const u8* iend, u32* offBasePtr, int lane)
+{   // zstd_lazy.c:1466-1487; vip = the 8 bytes at ip
+    return C.useRow ? zsa_row_findBestMatch(C, ip, vip, iend, offBasePtr, lane) : zsa_hc_findBestMatch(C, ip, vip, iend, offBasePtr, lane);
 }
 
 // depth 0 = greedy, 1 = lazy, 2 = lazy2 (zstd_lazy.c:1493-1757).  Appends packed sequences to seqOut, returns their
@@ -267,14 +261,16 @@ ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcS
         const u8* start = ip + 1;
         bool storeNow = false;
 
+        // the bytes at ip serve the repcode check at ip+1 and the search at ip; both loads share a round trip
+        u64 vip = wv_ldg64(ip);
         // :1578-1582 repcode at ip+1
-        if ((offset_1 > 0) && (wv_ldg32(ip + 1 - offset_1) == wv_ldg32(ip + 1))) {
+        if ((offset_1 > 0) && (wv_ldg32(ip + 1 - offset_1) == (u32)(vip >> 8))) {
             matchLength = zsa_dfast_count(ip + 1 + 4, ip + 1 + 4 - offset_1, iend) + 4;
             if (depth == 0) storeNow = true;
         }
         if (!storeNow) {
             {   u32 offbaseFound = 999999999;   // :1585-1589
-                u32 const ml2 = zsa_searchMax(C, ip, iend, &offbaseFound, lane);
+                u32 const ml2 = zsa_searchMax(C, ip, vip, iend, &offbaseFound, lane);
                 if (ml2 > matchLength) { matchLength = ml2; start = ip; offBase = offbaseFound; }
             }
             if (matchLength < 4) {   // :1591-1603
@@ -286,28 +282,30 @@ ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcS
             if (depth >= 1)
             while (ZSA_BEFORE_LIMIT(ip)) {   // :1606-1678
                 ip++;
-                if ((offBase) && ((offset_1 > 0) && (wv_ldg32(ip) == wv_ldg32(ip - offset_1)))) {
+                vip = wv_ldg64(ip);
+                if ((offBase) && ((offset_1 > 0) && ((u32)vip == wv_ldg32(ip - offset_1)))) {
                     u32 const mlRep = zsa_dfast_count(ip + 4, ip + 4 - offset_1, iend) + 4;
                     s32 const gain2 = (s32)(mlRep * 3);
                     s32 const gain1 = (s32)(matchLength * 3 - ZSA_HB(offBase) + 1);
                     if ((mlRep >= 4) && (gain2 > gain1)) { matchLength = mlRep; offBase = 1; start = ip; }
                 }
                 {   u32 ofbCandidate = 999999999;
-                    u32 const ml2 = zsa_searchMax(C, ip, iend, &ofbCandidate, lane);
+                    u32 const ml2 = zsa_searchMax(C, ip, vip, iend, &ofbCandidate, lane);
                     s32 const gain2 = (s32)(ml2 * 4 - ZSA_HB(ofbCandidate));
                     s32 const gain1 = (s32)(matchLength * 4 - ZSA_HB(offBase) + 4);
                     if ((ml2 >= 4) && (gain2 > gain1)) { matchLength = ml2; offBase = ofbCandidate; start = ip; continue; }
                 }
                 if ((depth == 2) && ZSA_BEFORE_LIMIT(ip)) {
                     ip++;
-                    if ((offBase) && ((offset_1 > 0) && (wv_ldg32(ip) == wv_ldg32(ip - offset_1)))) {
+                    vip = wv_ldg64(ip);
+                    if ((offBase) && ((offset_1 > 0) && ((u32)vip == wv_ldg32(ip - offset_1)))) {
                         u32 const mlRep = zsa_dfast_count(ip + 4, ip + 4 - offset_1, iend) + 4;
                         s32 const gain2 = (s32)(mlRep * 4);
                         s32 const gain1 = (s32)(matchLength * 4 - ZSA_HB(offBase) + 1);
                         if ((mlRep >= 4) && (gain2 > gain1)) { matchLength = mlRep; offBase = 1; start = ip; }
                     }
                     {   u32 ofbCandidate = 999999999;
-                        u32 const ml2 = zsa_searchMax(C, ip, iend, &ofbCandidate, lane);
+                        u32 const ml2 = zsa_searchMax(C, ip, vip, iend, &ofbCandidate, lane);
                         s32 const gain2 = (s32)(ml2 * 4 - ZSA_HB(ofbCandidate));
                         s32 const gain1 = (s32)(matchLength * 4 - ZSA_HB(offBase) + 7);
                         if ((ml2 >= 4) && (gain2 > gain1)) { matchLength = ml2; offBase = ofbCandidate; start = ip; continue; }
@@ -317,7 +315,19 @@ ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcS
             }
             if (offBase > 3) {   // :1685-1698 catch up
                 u32 const off = offBase - 3;
-                while (((start > anchor) & (start - off > prefixLowest)) && (wv_ldg8(start - 1) == wv_ldg8(start - off - 1))) { start--; matchLength++; }
+                const u8* const m = start - off;
+                u32 const roomA = (u32)(start - anchor), roomM = (u32)(m - prefixLowest);   // start > anchor & match > prefixLowest
+                u32 const maxBack = roomA < roomM ? roomA : roomM;
+                u32 back = 0;
+                if (maxBack > 0 && roomM >= 8) {   // 8 bytes before both in one round trip
+                    u64 const d = wv_ldg64(start - 8) ^ wv_ldg64(m - 8);
+                    back = d ? ((u32)__builtin_clzll(d) >> 3) : 8;
+                    if (back > maxBack) back = maxBack;
+                    if (back == 8) while (back < maxBack && wv_ldg8(start - 1 - back) == wv_ldg8(m - 1 - back)) back++;
+                } else {
+                    while (back < maxBack && wv_ldg8(start - 1 - back) == wv_ldg8(m - 1 - back)) back++;
+                }
+                start -= back; matchLength += back;
                 offset_2 = offset_1; offset_1 = off;
             }
         }
