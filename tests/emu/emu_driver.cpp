@@ -68,7 +68,8 @@ struct EncArgs { ZsaEncShared* S; u32* ht; ZsaEncParams P; const u8* src; u64 sr
 static void enc_entry(void* a)
 {
     EncArgs* A = (EncArgs*)a;
-    u64 r = zsa_encode_frame(A->S, A->ht, A->P, A->src, A->srcSize, A->dst, A->cap, A->W, A->cd, A->dictMode);
+    u64 r = A->P.strat >= 3 ? zsa_encode_frame<1>(A->S, A->ht, A->P, A->src, A->srcSize, A->dst, A->cap, A->W, A->cd, A->dictMode)
+                            : zsa_encode_frame<0>(A->S, A->ht, A->P, A->src, A->srcSize, A->dst, A->cap, A->W, A->cd, A->dictMode);
     if (wv_lane() == 0) A->result = r;
 }
 extern "C" size_t emu_compress(void* dst, size_t cap, const void* src, size_t n, unsigned wlog, unsigned hlog, unsigned mml, unsigned tlen)

@@ -1566,6 +1566,9 @@ ZSA_DEV void zsa_gatherLiterals(ZsaEncShared* S, const u64* seq, u32 nbSeq, cons
 // Returns bytes written or (u64)-error (uniform).
 struct ZsaEncScratch { u64* seq; u8* lit; u8* tmp; ZsaFseCT* park; };   // park: 3 sequence tables (LL, OF, ML) of the last compressed block
 
+// FAMILY 0: ZSTD_fast / ZSTD_dfast (and the dictionary variants); FAMILY 1: ZSTD_greedy / ZSTD_lazy / ZSTD_lazy2.  The two
+// are compiled into separate kernels: each parser then gets the whole register budget (one kernel holding both spilled).
+template <int FAMILY>
 ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams& P, const u8* src, u64 srcSize64,
                              u8* dst, u64 dstCapacity, const ZsaEncScratch& W, const ZsaCDictDev* cd, int dictMode)
 {
@@ -1712,7 +1715,7 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
                 u32 const curr = (u32)(ip - Wn.base);
                 if (curr > LZ.nextToUpdate + 384) { u32 const gap = curr - LZ.nextToUpdate - 384; LZ.nextToUpdate = curr - (gap < 192 ? gap : 192); }
             }
-            bool const dictParse = (Wn.lowLimit < Wn.dictLimit) || (Wn.dms != nullptr);
+            bool const dictParse = FAMILY == 0 && ((Wn.lowLimit < Wn.dictLimit) || (Wn.dms != nullptr));
             if (dictParse && lane == 0) {   // dictionary variants: serial (small payloads; many frames in flight instead)
                 u32 rep[3] = { S->prevRep[0], S->prevRep[1], S->prevRep[2] };
                 u32 lastLL = 0;
@@ -1727,7 +1730,7 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
                 wv_sync();
                 u32 rep[3] = { S->prevRep[0], S->prevRep[1], S->prevRep[2] };
                 u32 lastLL = 0, nbSeq;
-                if (P.strat >= 3) {   // greedy / lazy / lazy2 (never with a dictionary here): wave-uniform, zsa_lazy.h
+                if (FAMILY == 1) {   // greedy / lazy / lazy2 (never with a dictionary here): wave-uniform, zsa_lazy.h
                     nbSeq = zsa_parse_lazy(LZ, Wn.dictLimit, ip, blockSize, P.strat - 3, rep, W.seq, &lastLL, lane);
                 } else if (P.strat == 2) {   // ZSTD_dfast (never with a dictionary here): serial for now, zsa_dfast.h
                     nbSeq = 0;
@@ -1760,8 +1763,10 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
             zsa_gatherLiterals(S, W.seq, nbSeq, ip, blockSize, lastLL, W.lit, lane);
             wv_sync();
             ZSA_PROF(S, lane, 2);
-            cSize = zsa_entropyCompress(S, W.seq, nbSeq, W.lit, litSize, op + 3, blockSize, W.tmp, literalsDisabled, cd, P.strat,
-                                        (P.strat >= 4 && !cd) ? W.park : (const ZsaFseCT*)0, lane);
+            // (FAMILY 0: the strategy is 1 or 2, which folds the cost-based mode selection out of that kernel)
+            u32 const strat = FAMILY == 0 ? (P.strat == 2 ? 2u : 1u) : P.strat;
+            cSize = zsa_entropyCompress(S, W.seq, nbSeq, W.lit, litSize, op + 3, blockSize, W.tmp, literalsDisabled, cd, strat,
+                                        (FAMILY == 1 && P.strat >= 4 && !cd) ? W.park : (const ZsaFseCT*)0, lane);
             if (S->err) return ZSA_ERR(S->err);
             tablesBuilt = nbSeq != 0;
             if (!isFirstBlock && cSize < 25) {   // zstd_compress.c:4258-4269 (ZSTD_isRLE :3413-3433)
@@ -1777,7 +1782,7 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
             S->prevHufRepeat = S->nextHufRepeat; S->prevLL = S->nextLL; S->prevOF = S->nextOF; S->prevML = S->nextML;
         }
         if (cSize > 1) for (u32 i = (u32)lane; i < 256; i += ZSA_WAVE) { S->hufPrev.nbBits[i] = S->hufNext.nbBits[i]; S->hufPrev.val[i] = S->hufNext.val[i]; }
-        if (cSize > 1 && tablesBuilt && P.strat >= 4 && !cd && !lastBlock) {
+        if (FAMILY == 1 && cSize > 1 && tablesBuilt && P.strat >= 4 && !cd && !lastBlock) {
             // a later block may price or repeat these tables (zstd_compress_sequences.c:206-232): park them before the next
             // parse reuses their LDS.  A block without sequences leaves the parked ones in place (zstd_compress.c:2901-2906).
             const u32* const from[3] = { (const u32*)&S->ll, (const u32*)&S->of, (const u32*)&S->ml };

@@ -49,7 +49,39 @@ struct ZsaLazyCtx {
     u32 nextToUpdate;        // first index not yet entered into the tables; lives across the blocks of a frame
     u32 lazySkipping;
     bool useRow;
+    // row cache (registers): the rows of positions cBase .. cBase + cN - 1 as they are in memory now.  Lane L holds tag
+    // byte and cell (L & rowMask) of the row of position cBase + (L >> rowLog), and that row's offset in cRel.  A search
+    // that misses fills it for its own and the next positions in the one round trip it needs anyway; entering a position
+    // into a row patches the cached copy, a table update after a match drops it.
+    u32 cBase, cN;
+    u32 cTag, cCell, cRel;
 };
+
+// 16 source bytes at `p`, kept in registers: literal runs are searched position after position, and the bytes a position
+// needs (8 at ip for the hash, 4 at ip+1-offset for the repcode check) mostly lie in what the previous position loaded.
+struct ZsaSrcWin { const u8* p; u32 max8, max4; u64 lo, hi; };
+ZSA_DEV void zsa_win_fill(ZsaSrcWin& W, const u8* p, const u8* iend)
+{
+    bool const both = p + 16 <= iend;
+    W.p = p; W.lo = wv_ldg64(p); W.hi = both ? wv_ldg64(p + 8) : 0;
+    W.max8 = both ? 8u : 0u; W.max4 = both ? 12u : 4u;
+}
+ZSA_DEV u64 zsa_win_at(const ZsaSrcWin& W, u32 d)   // 8 bytes at offset d <= 8 (bytes past offset 16 read as zero)
+{
+    return d == 0 ? W.lo : (d >= 8 ? (W.hi >> (8u * (d - 8u))) : ((W.lo >> (8u * d)) | (W.hi << (64u - 8u * d))));
+}
+ZSA_DEV u64 zsa_win_get64(ZsaSrcWin& W, const u8* p, const u8* iend)
+{
+    size_t const d = (size_t)(p - W.p);
+    if (!(W.p && d <= W.max8)) { zsa_win_fill(W, p, iend); return W.lo; }
+    return zsa_win_at(W, (u32)d);
+}
+ZSA_DEV u32 zsa_win_get32(ZsaSrcWin& W, const u8* p, const u8* iend)
+{
+    size_t const d = (size_t)(p - W.p);
+    if (!(W.p && d <= W.max4)) { zsa_win_fill(W, p, iend); return (u32)W.lo; }
+    return (u32)zsa_win_at(W, (u32)d);
+}
 
 // ---------------------------------------------------------------- candidate evaluation, one candidate per lane
 // Both finders walk their candidates in a fixed order and keep the first one that is strictly longer than everything
@@ -60,13 +92,14 @@ struct ZsaLazyCtx {
 ZSA_DEV void zsa_lazy_evaluate(const ZsaLazyCtx& C, const u8* ip, const u8* iLimit, u32 curr, u32 myIndex, u32 nCand,
                                u32* ml, u32* offBasePtr, int lane)
 {
+    if (nCand == 0) return;
     bool const mine = (u32)lane < nCand;
     u32 const len = mine ? zsa_dfast_count(ip, C.base + myIndex, iLimit) : 0u;
-    u32 const best = wv_reduce_max(len);
-    if (best > *ml) {
-        int const which = __builtin_ctzll(wv_ballot(mine && len == best));
+    u32 best = *ml, which = ZSA_WAVE;
+    for (u32 k = 0; k < nCand; k++) { u32 const l = wv_readlane(len, (int)k); if (l > best) { best = l; which = k; } }   // first maximum
+    if (which < ZSA_WAVE) {
         *ml = best;
-        *offBasePtr = (curr - wv_readlane(myIndex, which)) + 3;
+        *offBasePtr = (curr - wv_readlane(myIndex, (int)which)) + 3;
     }
 }
 
@@ -135,6 +168,10 @@ ZSA_DEV void zsa_row_put(ZsaLazyCtx& C, u32 relRow, u32 tag, u32 idx, u32 rowMas
     u32 next = (head - 1u) & rowMask;
     next += (next == 0) ? rowMask : 0;
     if (lane == 0) { wv_stg8(tagRow, next); wv_stg8(tagRow + next, tag); wv_stg_cell(C.hashTable + relRow + next, idx); }
+    if (C.cRel == relRow && ((u32)lane >> C.rowLog) < C.cN) {   // the cached copies of this row
+        if (((u32)lane & rowMask) == next) { C.cTag = tag; C.cCell = idx; }
+        if (((u32)lane & rowMask) == 0) C.cTag = next;
+    }
 }
 // zstd_lazy.c:867-890 ZSTD_row_update_internalImpl for positions [from, to), 64 per step: lane k takes position
 // from + k.  The reference enters them one after the other; the only coupling between two of them is the head of a row
@@ -144,6 +181,7 @@ ZSA_DEV void zsa_row_put(ZsaLazyCtx& C, u32 relRow, u32 tag, u32 idx, u32 rowMas
 // bytes) is not stored at all, which is what overwriting would have left.
 ZSA_DEV void zsa_row_insert_range(ZsaLazyCtx& C, u32 from, u32 to, u32 rowMask, int lane)
 {
+    if (from < to) C.cN = 0;
     for (u32 b = from; b < to; b += ZSA_WAVE) {
         u32 const n = (to - b) < ZSA_WAVE ? (to - b) : ZSA_WAVE;
         bool const act = (u32)lane < n;
@@ -178,7 +216,7 @@ ZSA_DEV void zsa_row_update(ZsaLazyCtx& C, const u8* ip, u32 rowMask, int lane)
     C.nextToUpdate = target;
 }
 // zstd_lazy.c:1120-1313 ZSTD_RowFindBestMatch, noDict
-ZSA_DEV u32 zsa_row_findBestMatch(ZsaLazyCtx& C, const u8* ip, u64 vip, const u8* iLimit, u32* offBasePtr, int lane)
+ZSA_DEV u32 zsa_row_findBestMatch(ZsaLazyCtx& C, const u8* ip, u64 vip, const ZsaSrcWin& W, const u8* iLimit, u32* offBasePtr, int lane)
 {
     u32 const curr = (u32)(ip - C.base);
     u32 const maxDistance = 1u << C.wlog;
@@ -196,25 +234,44 @@ ZSA_DEV u32 zsa_row_findBestMatch(ZsaLazyCtx& C, const u8* ip, u64 vip, const u8
     u32 const tag = hash & 0xFF;
     // :1040-1102 the match mask and the row's cells in one round trip: lane p reads tag byte p and cell p of the row
     // (rowEntries <= 64), so "bit p set iff tagRow[p] == tag" is one ballot
-    bool const inRow = (u32)lane < rowEntries;
-    u32 const myTag = wv_ldg8(C.tagTable + relRow + (inRow ? (u32)lane : 0u));
-    u32 const myCell = wv_ldg_cell(C.hashTable + relRow + (inRow ? (u32)lane : 0u));
-    u64 const eq = wv_ballot(inRow && myTag == tag);
-    u32 const headByte = wv_readlane(myTag, 0), head = headByte & rowMask;
-    // :1205-1222: candidates from the newest (head) to the oldest; position 0 holds the head byte, not an entry.  Lane k
-    // takes the k-th of them; the list ends before the first index below lowLimit.
+    if (!(curr - C.cBase < C.cN)) {
+        // miss: read this position's row and, in the same round trip, the rows of the next positions whose bytes are at
+        // hand (group j of lanes = position curr + j)
+        u32 const j = (u32)lane >> C.rowLog;
+        size_t const d0 = (size_t)(ip - W.p);
+        bool const have = W.p && d0 <= W.max8;                        // ip's bytes came from the window
+        u32 const dj = (u32)d0 + j;
+        bool const known = j == 0 || (have && dj <= W.max8);
+        u64 const vj = j == 0 ? vip : zsa_win_at(W, known ? dj : 0u);
+        u32 const hj = zsa_hash_salted(vj, C.rowHashLog + 8, C.mls, ZSA_FRESH_HASH_SALT);
+        u32 const relj = known ? ((hj >> 8) << C.rowLog) : relRow;
+        C.cTag = wv_ldg8(C.tagTable + relj + ((u32)lane & rowMask));
+        C.cCell = wv_ldg_cell(C.hashTable + relj + ((u32)lane & rowMask));
+        C.cRel = relj;
+        C.cBase = curr;
+        u32 const groups = (u32)ZSA_WAVE >> C.rowLog;
+        u32 const avail = have ? (W.max8 - (u32)d0 + 1u) : 1u;
+        C.cN = groups < avail ? groups : avail;
+    }
+    // the group of lanes that holds this position's row; "bit p set iff tagRow[p] == tag" is that group's part of one ballot
+    u32 const g0 = (curr - C.cBase) << C.rowLog;
+    u64 eqAll = wv_ballot(C.cTag == tag) >> g0;
+    if (rowEntries < 64) eqAll &= (((u64)1 << rowEntries) - 1u);
+    u64 const eq = eqAll;
+    u32 const headByte = wv_readlane(C.cTag, (int)g0), head = headByte & rowMask;
+    // :1205-1222: candidates from the newest (head) to the oldest; position 0 holds the head byte, not an entry; the list
+    // ends before the first index below lowLimit.  Lane k keeps the k-th of them.
     u32 myIndex = 0, nCand = 0;
     {   u64 rot = head ? ((eq >> head) | (eq << (rowEntries - head))) : eq;
         if (rowEntries < 64) rot &= (((u64)1 << rowEntries) - 1u);
-        rot &= ~((u64)1 << ((rowEntries - head) & rowMask));           // the bit of position 0
-        u32 myPos = 0;
         for (; rot && nCand < nbAttempts; rot &= rot - 1) {
-            if ((u32)lane == nCand) myPos = (head + (u32)__builtin_ctzll(rot)) & rowMask;
+            u32 const matchPos = (head + (u32)__builtin_ctzll(rot)) & rowMask;
+            if (matchPos == 0) continue;
+            u32 const matchIndex = wv_readlane(C.cCell, (int)(g0 + matchPos));
+            if (matchIndex < lowLimit) break;
+            if ((u32)lane == nCand) myIndex = matchIndex;
             nCand++;
         }
-        myIndex = wv_shfl(myCell, (int)myPos);
-        u64 const low = wv_ballot((u32)lane < nCand && myIndex < lowLimit);
-        if (low) nCand = (u32)__builtin_ctzll(low);
     }
     wv_lds_fence();
     zsa_row_put(C, relRow, tag, C.nextToUpdate++, rowMask, headByte, lane);   // :1224-1230 the current position enters the row right away
@@ -225,9 +282,9 @@ ZSA_DEV u32 zsa_row_findBestMatch(ZsaLazyCtx& C, const u8* ip, u64 vip, const u8
     return ml;
 }
 
-ZSA_DEV u32 zsa_searchMax(ZsaLazyCtx& C, const u8* ip, u64 vip, const u8* iend, u32* offBasePtr, int lane)
-{   // zstd_lazy.c:1466-1487; vip = the 8 bytes at ip
-    return C.useRow ? zsa_row_findBestMatch(C, ip, vip, iend, offBasePtr, lane) : zsa_hc_findBestMatch(C, ip, vip, iend, offBasePtr, lane);
+ZSA_DEV u32 zsa_searchMax(ZsaLazyCtx& C, const u8* ip, u64 vip, const ZsaSrcWin& W, const u8* iend, u32* offBasePtr, int lane)
+{   // zstd_lazy.c:1466-1487; vip = the 8 bytes at ip, W = the source window they came from
+    return C.useRow ? zsa_row_findBestMatch(C, ip, vip, W, iend, offBasePtr, lane) : zsa_hc_findBestMatch(C, ip, vip, iend, offBasePtr, lane);
 }
 
 // depth 0 = greedy, 1 = lazy, 2 = lazy2 (zstd_lazy.c:1493-1757).  Appends packed sequences to seqOut, returns their
@@ -254,6 +311,9 @@ ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcS
         if (offset_1 > maxRep) { saved1 = offset_1; offset_1 = 0; }
     }
     C.lazySkipping = 0;
+    C.cN = 0; C.cBase = 0;
+    ZsaSrcWin W, R;   // source bytes around ip, and around ip - offset_1
+    W.p = R.p = nullptr; W.max8 = W.max4 = R.max8 = R.max4 = 0; W.lo = W.hi = R.lo = R.hi = 0;
 
     while (ZSA_BEFORE_LIMIT(ip)) {
         u32 matchLength = 0;
@@ -262,15 +322,15 @@ ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcS
         bool storeNow = false;
 
         // the bytes at ip serve the repcode check at ip+1 and the search at ip; both loads share a round trip
-        u64 vip = wv_ldg64(ip);
+        u64 vip = zsa_win_get64(W, ip, iend);
         // :1578-1582 repcode at ip+1
-        if ((offset_1 > 0) && (wv_ldg32(ip + 1 - offset_1) == (u32)(vip >> 8))) {
+        if ((offset_1 > 0) && (zsa_win_get32(R, ip + 1 - offset_1, iend) == (u32)(vip >> 8))) {
             matchLength = zsa_dfast_count(ip + 1 + 4, ip + 1 + 4 - offset_1, iend) + 4;
             if (depth == 0) storeNow = true;
         }
         if (!storeNow) {
             {   u32 offbaseFound = 999999999;   // :1585-1589
-                u32 const ml2 = zsa_searchMax(C, ip, vip, iend, &offbaseFound, lane);
+                u32 const ml2 = zsa_searchMax(C, ip, vip, W, iend, &offbaseFound, lane);
                 if (ml2 > matchLength) { matchLength = ml2; start = ip; offBase = offbaseFound; }
             }
             if (matchLength < 4) {   // :1591-1603
@@ -282,30 +342,30 @@ ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcS
             if (depth >= 1)
             while (ZSA_BEFORE_LIMIT(ip)) {   // :1606-1678
                 ip++;
-                vip = wv_ldg64(ip);
-                if ((offBase) && ((offset_1 > 0) && ((u32)vip == wv_ldg32(ip - offset_1)))) {
+                vip = zsa_win_get64(W, ip, iend);
+                if ((offBase) && ((offset_1 > 0) && ((u32)vip == zsa_win_get32(R, ip - offset_1, iend)))) {
                     u32 const mlRep = zsa_dfast_count(ip + 4, ip + 4 - offset_1, iend) + 4;
                     s32 const gain2 = (s32)(mlRep * 3);
                     s32 const gain1 = (s32)(matchLength * 3 - ZSA_HB(offBase) + 1);
                     if ((mlRep >= 4) && (gain2 > gain1)) { matchLength = mlRep; offBase = 1; start = ip; }
                 }
                 {   u32 ofbCandidate = 999999999;
-                    u32 const ml2 = zsa_searchMax(C, ip, vip, iend, &ofbCandidate, lane);
+                    u32 const ml2 = zsa_searchMax(C, ip, vip, W, iend, &ofbCandidate, lane);
                     s32 const gain2 = (s32)(ml2 * 4 - ZSA_HB(ofbCandidate));
                     s32 const gain1 = (s32)(matchLength * 4 - ZSA_HB(offBase) + 4);
                     if ((ml2 >= 4) && (gain2 > gain1)) { matchLength = ml2; offBase = ofbCandidate; start = ip; continue; }
                 }
                 if ((depth == 2) && ZSA_BEFORE_LIMIT(ip)) {
                     ip++;
-                    vip = wv_ldg64(ip);
-                    if ((offBase) && ((offset_1 > 0) && ((u32)vip == wv_ldg32(ip - offset_1)))) {
+                    vip = zsa_win_get64(W, ip, iend);
+                    if ((offBase) && ((offset_1 > 0) && ((u32)vip == zsa_win_get32(R, ip - offset_1, iend)))) {
                         u32 const mlRep = zsa_dfast_count(ip + 4, ip + 4 - offset_1, iend) + 4;
                         s32 const gain2 = (s32)(mlRep * 4);
                         s32 const gain1 = (s32)(matchLength * 4 - ZSA_HB(offBase) + 1);
                         if ((mlRep >= 4) && (gain2 > gain1)) { matchLength = mlRep; offBase = 1; start = ip; }
                     }
                     {   u32 ofbCandidate = 999999999;
-                        u32 const ml2 = zsa_searchMax(C, ip, vip, iend, &ofbCandidate, lane);
+                        u32 const ml2 = zsa_searchMax(C, ip, vip, W, iend, &ofbCandidate, lane);
                         s32 const gain2 = (s32)(ml2 * 4 - ZSA_HB(ofbCandidate));
                         s32 const gain1 = (s32)(matchLength * 4 - ZSA_HB(offBase) + 7);
                         if ((ml2 >= 4) && (gain2 > gain1)) { matchLength = ml2; offBase = ofbCandidate; start = ip; continue; }

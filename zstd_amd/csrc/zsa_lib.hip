@@ -60,12 +60,15 @@ zsa_k_decompress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ resu
     if (prof && threadIdx.x == 0) for (int i = 0; i < ZSA_NPROF; i++) atomicAdd((unsigned long long*)&prof[i], (unsigned long long)S.prof[i]);
 }
 
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZSA_ENC_WAVES, ZSA_ENC_WAVES)))
-zsa_k_compress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
-               u32* __restrict__ counter, u8* __restrict__ scratch, int level, const ZsaCDictDev* cd, u64* __restrict__ prof)
+// One persistent compress kernel per parser family (zsa_encode.h).  A launch at level 4 needs both (clevels.h mixes
+// ZSTD_dfast and ZSTD_greedy rows there, chosen per frame by its size): each kernel then walks all frames with a counter of
+// its own and takes the ones of its family; `reportUnsupported` says which of the two writes the error word of a frame
+// neither can take (0: not this one, 1: this one, 2: this one, and it is the only launch).
+template <int FAMILY>
+ZSA_DEV void zsa_compress_body(ZsaEncShared& S, u32& nextFrame, const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
+                               u32* __restrict__ counter, u8* __restrict__ scratch, int level, const ZsaCDictDev* cd, int reportUnsupported,
+                               u64* __restrict__ prof)
 {
-    __shared__ ZsaEncShared S;
-    __shared__ u32 nextFrame;
     if (threadIdx.x == 0) { for (int i = 0; i < ZSA_NPROF; i++) S.prof[i] = 0; S.profLast = wv_clock(); }
     u8* const wg = scratch + (size_t)blockIdx.x * ZSA_ENC_SCRATCH_BYTES;
     ZsaEncScratch W;
@@ -81,21 +84,41 @@ zsa_k_compress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ result
         ZsaFrameDesc const d = frames[f];
         ZSA_PROF(&S, threadIdx.x, 11);
         ZsaCParams cp;
-        u64 r;
         int dictMode = zsa_dm_none;
         int const bad = cd ? zsa_resolveCDictUse(&cp, &dictMode, cd->cp, cd->level, cd->dictSize, d.srcSize)
                            : zsa_resolveCParams(&cp, level, d.srcSize, 0, zsa_cpm_noAttachDict);
         // strategies: ZSTD_fast, and ZSTD_dfast .. ZSTD_lazy2 without a dictionary; the tables must fit the workgroup's scratch
         size_t const tableBytes = bad ? 0 : ((size_t)4 << cp.hlog) + zsa_auxTableBytes(cp.strat, cp.wlog, cp.hlog, cp.clog);
-        if (bad || !(cp.strat == 1 || (cp.strat >= 2 && cp.strat <= 5 && !cd)) || tableBytes > ZSA_HT_BYTES) r = ZSA_ERR(ZSA_parameter_unsupported);
-        else {
+        bool const unsupported = bad || !(cp.strat == 1 || (cp.strat >= 2 && cp.strat <= 5 && !cd)) || tableBytes > ZSA_HT_BYTES;
+        if (unsupported) {
+            if (reportUnsupported && threadIdx.x == 0) results[f] = ZSA_ERR(ZSA_parameter_unsupported);
+        } else if ((cp.strat >= 3) == (FAMILY == 1)) {
             ZsaEncParams P; P.wlog = cp.wlog; P.hlog = cp.hlog; P.mml = cp.mml; P.tlen = cp.tlen; P.clog = cp.clog; P.strat = cp.strat; P.slog = cp.slog;
-            r = zsa_encode_frame(&S, zsa_hashTable, P, d.src, d.srcSize, d.dst, d.dstCapacity, W, cd, dictMode);
+            u64 const r = zsa_encode_frame<FAMILY>(&S, zsa_hashTable, P, d.src, d.srcSize, d.dst, d.dstCapacity, W, cd, dictMode);
+            if (threadIdx.x == 0) results[f] = r;
+        } else if (reportUnsupported == 2) {   // the only launch, and the frame is not of its family: no row of clevels.h does that
+            if (threadIdx.x == 0) results[f] = ZSA_ERR(ZSA_parameter_unsupported);
         }
-        if (threadIdx.x == 0) results[f] = r;
         __syncthreads();
     }
     if (prof && threadIdx.x == 0) for (int i = 0; i < ZSA_NPROF; i++) atomicAdd((unsigned long long*)&prof[i], (unsigned long long)S.prof[i]);
+}
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZSA_ENC_WAVES, ZSA_ENC_WAVES)))
+zsa_k_compress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
+               u32* __restrict__ counter, u8* __restrict__ scratch, int level, const ZsaCDictDev* cd, int reportUnsupported, u64* __restrict__ prof)
+{
+    __shared__ ZsaEncShared S;
+    __shared__ u32 nextFrame;
+    zsa_compress_body<0>(S, nextFrame, frames, results, nFrames, counter, scratch, level, cd, reportUnsupported, prof);
+}
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZSA_ENC_WAVES, ZSA_ENC_WAVES)))
+zsa_k_compress_lazy(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
+                    u32* __restrict__ counter, u8* __restrict__ scratch, int level, const ZsaCDictDev* cd, int reportUnsupported, u64* __restrict__ prof)
+{
+    __shared__ ZsaEncShared S;
+    __shared__ u32 nextFrame;
+    zsa_compress_body<1>(S, nextFrame, frames, results, nFrames, counter, scratch, level, cd, reportUnsupported, prof);
 }
 
 __global__ void zsa_k_link_sizes(ZsaFrameDesc* __restrict__ frames, const u64* __restrict__ results, u32 n)
@@ -322,9 +345,17 @@ extern "C" size_t zsa_compress_enqueue(zsa_batch* b, int level, const zsa_CDict*
     std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)zsa_k_compress, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); });
     unsigned const grid = zsa_grid(b, ldsPerWG);
     HIPCHK(hipMemsetAsync(b->d_counter, 0, 256, (hipStream_t)stream));
-    hipLaunchKernelGGL(zsa_k_compress, dim3(grid), dim3(64), dynLds, (hipStream_t)stream,
-                       b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter, b->d_encScratch, level,
-                       cdict ? (const ZsaCDictDev*)cdict->d_cd : (const ZsaCDictDev*)nullptr, b->profOn ? b->d_prof : (u64*)nullptr);
+    // which parser families the level's clevels.h rows need: ZSTD_fast/ZSTD_dfast up to level 4 (and with a dictionary),
+    // ZSTD_greedy/ZSTD_lazy/ZSTD_lazy2 from level 4 on
+    bool const fam0 = cdict || level <= 4, fam1 = !cdict && level >= 4;
+    const ZsaCDictDev* const cd = cdict ? (const ZsaCDictDev*)cdict->d_cd : (const ZsaCDictDev*)nullptr;
+    u64* const prof = b->profOn ? b->d_prof : (u64*)nullptr;
+    if (fam0)
+        hipLaunchKernelGGL(zsa_k_compress, dim3(grid), dim3(64), dynLds, (hipStream_t)stream,
+                           b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter, b->d_encScratch, level, cd, fam1 ? 1 : 2, prof);
+    if (fam1)   // same scratch: the two launches run one after the other on the stream
+        hipLaunchKernelGGL(zsa_k_compress_lazy, dim3(grid), dim3(64), dynLds, (hipStream_t)stream,
+                           b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter + 16, b->d_encScratch, level, cd, fam0 ? 0 : 2, prof);
     HIPCHK(hipGetLastError());
     b->lastWG = grid; b->lastLDS = (unsigned)ldsPerWG;
     return 0;
