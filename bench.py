@@ -230,7 +230,7 @@ def main():
 # HBM bytes per launch need PMC passes of their own (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE cannot ride along with a
 # timed run); tools/collect_profiles.sh runs them on this very command and tools/summarize_profiles.py commits the
 # per-launch averages, with the guide's gfx950 correction (FETCH_SIZE counts 128-B requests as 64 B: x2), to this file.
-PMC_SUMMARY = "profiles/r01_v9_pmc.json"
+PMC_SUMMARY = "profiles/r01_v10_pmc.json"
 
 
 def committed_traffic(n_frames, frame_bytes, level):

@@ -6,8 +6,10 @@
  * reference's ZSTD_isError()/ZSTD_getErrorName() (errors.go:21-34 string-matches them).
  *
  * Scope of the engine: compression at the levels whose strategy is ZSTD_fast (level 1 and the negative levels at every
- * size, level 2 above 256 KB and up to 128 KB) or ZSTD_dfast (levels 3 and 0 at every size, level 4 except at <= 16 KB
- * and in (128 KB, 256 KB], level 2 in (128 KB, 256 KB]; without a dictionary), byte-identical to libzstd 1.5.5;
+ * size, level 2 above 256 KB and up to 128 KB), ZSTD_dfast (levels 3 and 0 at every size, level 4 except at <= 16 KB
+ * and in (128 KB, 256 KB], level 2 in (128 KB, 256 KB]) or ZSTD_greedy / ZSTD_lazy / ZSTD_lazy2 (level 5 -- the default of
+ * the reference's Compress(), zstd.go:23 -- at every size; levels 4 to 12 wherever clevels.h selects one of the three, as
+ * long as the frame's match tables fit the 5 MiB a resident workgroup owns), byte-identical to libzstd 1.5.5;
  * dictionary compression (CDict) at the ZSTD_fast levels; decompression of any
  * Zstandard frame (concatenated and skippable frames, checksums, dictionaries) except legacy v0.x frames.
  * Anything else returns an error code -- there is no CPU fallback inside this library: every entry point
@@ -67,7 +69,7 @@ size_t zsa_decompress_batch(const void* const* src, const size_t* srcSize, void*
  *    A zsa_batch owns everything a launch needs (frame table, result words, per-workgroup scratch), so
  *    zsa_*_enqueue only put work on `stream` (a hipStream_t passed as void*; NULL = the default stream) and allocate
  *    nothing -- except the first zsa_compress_enqueue on a batch, which allocates that batch's compression workspace
- *    once (2.6 MiB per resident workgroup).  All device pointers must belong to the current HIP device.
+ *    once (5.6 MiB per resident workgroup).  All device pointers must belong to the current HIP device.
  * ------------------------------------------------------------------------------------------------------- */
 typedef struct zsa_batch_s zsa_batch;
 zsa_batch* zsa_batch_create(size_t maxFrames);

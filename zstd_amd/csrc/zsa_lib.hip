@@ -270,7 +270,7 @@ extern "C" zsa_batch* zsa_batch_create(size_t maxFrames)
     size_t const wgs = maxFrames < maxWG ? maxFrames : maxWG;
     b->wgs = wgs;
     b->scratchBytes = wgs * ZSA_DEC_SCRATCH_BYTES;
-    b->encScratchBytes = wgs * ZSA_ENC_SCRATCH_BYTES;   // 2.6 MiB per resident workgroup: allocated by the first compress on this batch
+    b->encScratchBytes = wgs * ZSA_ENC_SCRATCH_BYTES;   // 5.6 MiB per resident workgroup: allocated by the first compress on this batch
     bool ok = hipHostMalloc((void**)&b->h_frames, maxFrames * sizeof(ZsaFrameDesc), hipHostMallocDefault) == hipSuccess
            && hipHostMalloc((void**)&b->h_results, maxFrames * sizeof(u64), hipHostMallocDefault) == hipSuccess
            && hipMalloc((void**)&b->d_frames, maxFrames * sizeof(ZsaFrameDesc)) == hipSuccess
