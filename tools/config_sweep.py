@@ -58,3 +58,6 @@ run("C3 1 KiB JSON payloads + trained dictionary", "json", 1024, 1 << 20, 7, 1, 
 run("C4 256 KiB log frames, level 1", "log", 262144, 8192, 43, 1)
 run("C5 1 MiB log chunks, level 3 (ZSTD_dfast)", "log", 1 << 20, 4096, 44, 3, steps=2)
 run("   128 KiB log frames, level 3 (ZSTD_dfast)", "log", 131072, 8192, 42, 3)
+run("   128 KiB log frames, level 5 (greedy, row hash)", "log", 131072, 8192, 42, 5, steps=2)
+run("   16 KiB log frames, level 5 (lazy, hash chain)", "log", 16384, 65536, 45, 5, steps=2)
+run("   128 KiB log frames, level 7 (lazy2, row hash)", "log", 131072, 8192, 42, 7, steps=2)
