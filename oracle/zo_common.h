@@ -4,10 +4,11 @@
  * product library (zstd_amd/).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
  * may use it, and only as the checker.
  *
- * The oracle is a plain-C restatement of the Zstandard level-1 ("ZSTD_fast") one-shot path of the
- * reference (DataDog/zstd, vendored libzstd 1.5.5).  Every function cites the reference file:line it
- * follows.  Parity is PINNED: tests/test_oracle_vs_ref.py compares it byte-for-byte with the reference's
- * own C compiled into oracle/_ref/libzstd_ref.so, and against the committed fixtures in tests/golden/.
+ * The oracle is a plain-C restatement of the one-shot path of the reference (DataDog/zstd, vendored libzstd 1.5.5):
+ * compression at the ZSTD_fast, ZSTD_dfast and ZSTD_greedy/ZSTD_lazy/ZSTD_lazy2 levels (dictionaries at ZSTD_fast),
+ * decompression of any frame.  Every function cites the reference file:line it follows.  Parity is PINNED:
+ * tests/test_oracle.py and tests/test_oracle_dict.py compare it byte-for-byte with the reference's own C compiled into
+ * oracle/_ref/libzstd_ref.so, and against the committed reference-generated fixtures in tests/golden/.
  */
 #ifndef ZO_COMMON_H
 #define ZO_COMMON_H
