@@ -69,7 +69,7 @@ def test_cparams_match_oracle(oracle):
     q = oracle.lib.zo_cparams_query
     q.argtypes = [ctypes.c_int, ctypes.c_ulonglong, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_uint)]
     out = (ctypes.c_uint * 7)()
-    for level in (-5, -1, 0, 1, 2, 3, 4):
+    for level in (-5, -1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13):
         for size in (0, 1, 63, 64, 1000, 1024, 8192, 8193, 16384, 16385, 65536, 131072, 131073, 262144, 262145, 1 << 20, 1 << 23, 2 ** 64 - 1):
             for dsize, mode in ((0, 0), (256, 2), (40000, 2), (256, 1)):
                 rc = q(level, size, dsize, mode if mode != 2 else 2, out)
@@ -77,3 +77,27 @@ def test_cparams_match_oracle(oracle):
                 assert (got is None) == (rc != 0)
                 if got is not None:
                     assert got == tuple(out), (level, size, dsize, mode)
+
+
+def test_cparams_match_reference(ref):
+    """the engine's clevels.h rows and ZSTD_adjustCParams_internal restatement (zsa_params.h) against the reference's own
+    ZSTD_getCParams (zstd_compress.c:7011-7016), every level it serves, across the size classes"""
+    import zstd_amd
+
+    class CP(ctypes.Structure):
+        _fields_ = [(n, ctypes.c_uint) for n in ("wlog", "clog", "hlog", "slog", "mml", "tlen", "strat")]
+    f = ref.lib.ZSTD_getCParams
+    f.restype = CP
+    f.argtypes = [ctypes.c_int, ctypes.c_ulonglong, ctypes.c_size_t]
+    n = 0
+    for level in (-7, -1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12):
+        for size in (1, 63, 64, 1000, 1024, 8192, 16384, 16385, 65536, 131072, 131073, 262144, 262145, 1 << 20, 1 << 23):
+            got = zstd_amd.getCParams(level, size)
+            r = f(level, size, 0)
+            want = (r.wlog, r.clog, r.hlog, r.slog, r.mml, r.tlen, r.strat)
+            if got is None:
+                assert r.strat > 5, (level, size, want)      # a btlazy2 / btopt row: outside the engine
+            else:
+                assert got == want, (level, size, got, want)
+                n += 1
+    assert n > 150
