@@ -13,6 +13,7 @@
 
 #define ZSA_DEV    static inline
 #define ZSA_DEVFN  static
+#define ZSA_MEM    inline
 #define ZSA_HD     static inline
 #define ZSA_SHARED static
 #define ZSA_WAVE   64
@@ -69,6 +70,16 @@ ZSA_DEV unsigned wv_shfl_xor(unsigned v, int mask, int line = __builtin_LINE()) 
 ZSA_DEV void wv_sync(int line = __builtin_LINE()) { (void)emu_collect(0, line); }
 ZSA_DEV void wv_lds_fence(int line = __builtin_LINE()) { (void)emu_collect(0, line); }
 ZSA_DEV unsigned wv_readlane(unsigned v, int srcLane, int line = __builtin_LINE()) { const uint64_t* a = emu_collect(v, line); return (unsigned)a[srcLane & 63]; }
+// wv_uniform: on the GPU a hint (readfirstlane); here a check that the value really is the same in all lanes
+void emu_not_uniform(int line);
+ZSA_DEV unsigned long long wv_uniform64(unsigned long long v, int line = __builtin_LINE())
+{
+    const uint64_t* a = emu_collect(v, line);
+    for (int i = 0; i < 64; i++) if (!g_emu.done[i] && a[i] != v) emu_not_uniform(line);
+    return v;
+}
+ZSA_DEV unsigned wv_uniform(unsigned v, int line = __builtin_LINE()) { return (unsigned)wv_uniform64(v, line); }
+ZSA_DEV bool wv_uniform_b(bool v, int line = __builtin_LINE()) { return wv_uniform64(v ? 1 : 0, line) != 0; }
 ZSA_DEV unsigned wv_alignbyte(unsigned hi, unsigned lo, unsigned sh) { return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (8 * (sh & 3))); }
 ZSA_DEV unsigned wv_ldg8(const unsigned char* p) { return *p; }
 ZSA_DEV unsigned wv_ldg32(const unsigned char* p) { unsigned v; memcpy(&v, p, 4); return v; }

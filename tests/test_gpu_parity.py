@@ -388,3 +388,73 @@ def test_bulk_destination_cases(z, oracle):
     assert bp.Compress(bytearray(1), REF_TEST_PAYLOAD) == want                  # dst too small: a new buffer is used
     assert bp.Decompress(bytearray(len(REF_TEST_PAYLOAD)), want) == REF_TEST_PAYLOAD
     assert bp.Decompress(bytearray(1), want) == REF_TEST_PAYLOAD                # dst too small: sized from the frame header
+
+
+def test_many_threads_single_call_api(z, oracle):
+    """zstd.go:95-129: the one-shot calls are lock-free and run on any goroutine.  64 threads call zsa_compress /
+    zsa_decompress at once; every result equals the oracle's, and the per-thread staging memory is returned when the
+    threads end: after a first round (the HIP runtime keeps what its own stream and queue pools grew to under 64 concurrent
+    callers), further rounds of 64 new threads leave hipMemGetInfo where it was."""
+    import threading
+    import torch
+    from zstd_amd import corpus
+    payloads = corpus.frames("json", 3000, 64, 11)
+    want = [oracle.compress(p, 1) for p in payloads]
+    errs = []
+
+    def work(i):
+        try:
+            for k in range(3):
+                p = payloads[(i + k) % 64]
+                c = z.CompressLevel(None, p, 1)
+                assert c == want[(i + k) % 64]
+                assert z.Decompress(None, c) == p
+        except Exception as e:   # noqa: BLE001
+            errs.append((i, repr(e)))
+
+    def round_of_threads():
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(64)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errs, errs[:3]
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0]
+
+    free0 = round_of_threads()
+    round_of_threads()
+    free2 = round_of_threads()
+    # (the runtime's pools move by some tens of MiB from round to round; the staging of 128 leaked threads would be > 2 GiB)
+    assert free2 >= free0 - (256 << 20), "per-thread staging leaked: %d MiB over 128 threads" % ((free0 - free2) >> 20)
+
+
+def test_capacity_contract(z, oracle):
+    """include/zstd_amd.h: dstCapacity >= zsa_compressBound(srcSize) is required; a smaller destination is refused with the
+    reference's "Destination buffer is too small" even where the frame would fit."""
+    from zstd_amd._lib import lib
+    p = b"abcd" * 1000
+    bound = z.CompressBound(len(p))
+    out = ctypes.create_string_buffer(bound)
+    src = ctypes.create_string_buffer(p, len(p))
+    r = lib.zsa_compress(ctypes.cast(out, ctypes.c_void_p), bound - 1, ctypes.cast(src, ctypes.c_void_p), len(p), 1)
+    assert lib.zsa_isError(r) and z.IsDstSizeTooSmallError(z.ErrorCode(r - 2 ** 64))
+    r = lib.zsa_compress(ctypes.cast(out, ctypes.c_void_p), bound, ctypes.cast(src, ctypes.c_void_p), len(p), 1)
+    assert out.raw[:r] == oracle.compress(p, 1)
+
+
+def test_lds_table_kernel_parity(z, oracle):
+    """The opt-in kernel that keeps the ZSTD_fast match table in LDS (24-bit cells, hoisted 64-position window,
+    zsa_parse.h): byte-identical like the default kernel, including the frames it leaves to the default kernel."""
+    from zstd_amd import corpus
+    rnd = random.Random(3)
+    frames = corpus.frames("log", 131072, 6, 42) + corpus.frames("json", 65536, 6, 1234) + corpus.frames("log", 262144, 2, 43) \
+        + corpus.frames("json", 1024, 16, 7) + [b"", b"a", bytes(5000), rnd.randbytes(3000), b"ab" * 5000,
+                                                 b"".join(rnd.choice([b"alpha ", b"beta ", b"gamma "]) for _ in range(9000)),
+                                                 corpus.frames("log", 600000, 1, 9)[0]]
+    os.environ["ZSA_LDS_TABLE"] = "1"
+    try:
+        for level in (1, 2, -1):
+            _check_compress(z, oracle, frames, level)
+    finally:
+        del os.environ["ZSA_LDS_TABLE"]

@@ -44,6 +44,9 @@ def _load():
         "zsa_decompress_enqueue": (S, [V, V, V]),
         "zsa_batch_results": (S, [V, c_size_p, V]),
         "zsa_batch_device_results": (V, [V]),
+        "zsa_batch_export_sizes_i32": (S, [V, V, V]),
+        "zsa_decompress_frames_noalloc": (S, [V, V, S, V, V]),
+        "zsa_thread_release": (None, []),
         "zsa_batch_last_launch": (None, [V, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]),
         "zsa_batch_profile": (S, [V, I, ctypes.POINTER(ctypes.c_uint64), V]),
         "zsa_getCParams": (I, [I, ctypes.c_ulonglong, S, I, ctypes.POINTER(ctypes.c_uint)]),

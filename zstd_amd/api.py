@@ -329,6 +329,12 @@ class DeviceBatch:
             raise ErrorCode(rc - 2 ** 64)
         return [out[i] for i in range(self.n)]
 
+    def export_sizes_i32(self, out_ptr, stream=None):
+        """result words -> int32 on the device (bytes, or -(error code)), into a caller-owned device buffer"""
+        rc = lib.zsa_batch_export_sizes_i32(self.h, out_ptr, stream)
+        if lib.zsa_isError(rc):
+            raise ErrorCode(rc - 2 ** 64)
+
     def profile(self, enable, read=False, stream=None):
         out = (ctypes.c_uint64 * 12)() if read else None
         lib.zsa_batch_profile(self.h, 1 if enable else 0, out, stream)

@@ -1566,11 +1566,19 @@ ZSA_DEV void zsa_gatherLiterals(ZsaEncShared* S, const u64* seq, u32 nbSeq, cons
 // Returns bytes written or (u64)-error (uniform).
 struct ZsaEncScratch { u64* seq; u8* lit; u8* tmp; ZsaFseCT* park; };   // park: 3 sequence tables (LL, OF, ML) of the last compressed block
 
-// FAMILY 0: ZSTD_fast / ZSTD_dfast (and the dictionary variants); FAMILY 1: ZSTD_greedy / ZSTD_lazy / ZSTD_lazy2.  The two
-// are compiled into separate kernels: each parser then gets the whole register budget (one kernel holding both spilled).
+// FAMILY 0: ZSTD_fast / ZSTD_dfast (and the dictionary variants); FAMILY 1: ZSTD_greedy / ZSTD_lazy / ZSTD_lazy2; FAMILY 2:
+// ZSTD_fast without a dictionary and with step 2 (levels 1 and 2), match table in LDS (`ldsTab`, 3 << hashLog bytes; the
+// global `hashTable` is not touched).  Each is compiled into a kernel of its own: each parser then gets the whole register
+// budget (one kernel holding two of them spilled).
+ZSA_HD bool zsa_ldsTableFits(u32 strat, u32 tlen, u32 hlog, u64 srcSize, size_t ldsTableBytes)
+{   // a 24-bit cell holds the position (indices run up to srcSize + 2) and at least 5 fingerprint bits
+    if (strat != 1 || tlen > 1 || srcSize == 0 || srcSize > (1u << 19) - 4) return false;
+    return ((size_t)3 << hlog) <= ldsTableBytes;
+}
 template <int FAMILY>
 ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams& P, const u8* src, u64 srcSize64,
-                             u8* dst, u64 dstCapacity, const ZsaEncScratch& W, const ZsaCDictDev* cd, int dictMode)
+                             u8* dst, u64 dstCapacity, const ZsaEncScratch& W, const ZsaCDictDev* cd, int dictMode,
+                             ZsaTabLds ldsTab = ZsaTabLds())
 {
     int const lane = wv_lane();
     if (srcSize64 > 0xE0000000ull) return ZSA_ERR(ZSA_srcSize_wrong);
@@ -1609,7 +1617,11 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
     // per-frame state (zstd_compress.c:2045-2225, 1863-1872; with a dictionary :2270-2329, :2347-2426, :5027-5044)
     ZsaWindow Wn;
     Wn.base = src - 2; Wn.dictBase = src - 2; Wn.dictLimit = 2; Wn.lowLimit = 2; Wn.loadedDictEnd = 0; Wn.dms = nullptr;
-    if (cd && dictMode == zsa_dm_copy) {   // ZSTD_copyCDictTableIntoCCtx: tags removed
+    if (FAMILY == 2) {
+        u32* const lo = (u32*)ldsTab.lo; u32* const hi = (u32*)ldsTab.hi;
+        for (u32 i = (u32)lane; i < (1u << P.hlog) / 2u; i += ZSA_WAVE) lo[i] = 0;
+        for (u32 i = (u32)lane; i < (1u << P.hlog) / 4u; i += ZSA_WAVE) hi[i] = 0;
+    } else if (cd && dictMode == zsa_dm_copy) {   // ZSTD_copyCDictTableIntoCCtx: tags removed
         for (u32 i = (u32)lane; i < (1u << P.hlog); i += ZSA_WAVE) hashTable[i] = cd->hashTable[i] >> 8;
     } else {
         // ZSTD_dfast: the short-hash ("chain") table follows the long one in the same scratch region; greedy/lazy/lazy2: the
@@ -1673,7 +1685,7 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
     // Without a dictionary the match table is touched by the wave parser only, which then keeps a fingerprint of the 4
     // bytes at each position in the cell bits the position does not need (zsa_parse.h); indices run up to srcSize + 2.
     u32 fpPosBits = 0;
-    if (!cd && P.strat == 1) { u32 const bits = 32u - (u32)__builtin_clz(srcSize + 2u); if (bits <= 26) fpPosBits = bits; }
+    if (!cd && P.strat == 1) { u32 const bits = 32u - (u32)__builtin_clz(srcSize + 2u); if (bits <= (FAMILY == 2 ? 19u : 26u)) fpPosBits = bits; }
     int const literalsDisabled = (P.strat == 1) && (P.tlen > 0);   // zstd_compress_internal.h:605-618
     u32 const maxDist = 1u << P.wlog;
     ZsaLazyCtx LZ;   // greedy / lazy / lazy2 (zsa_lazy.h): match-finder state that lives across the blocks of the frame
@@ -1732,6 +1744,8 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
                 u32 lastLL = 0, nbSeq;
                 if (FAMILY == 1) {   // greedy / lazy / lazy2 (never with a dictionary here): wave-uniform, zsa_lazy.h
                     nbSeq = zsa_parse_lazy(LZ, Wn.dictLimit, ip, blockSize, P.strat - 3, rep, W.seq, &lastLL, lane);
+                } else if (FAMILY == 2) {   // ZSTD_fast, table in LDS: hoisted-window parse (zsa_parse.h)
+                    nbSeq = zsa_parse_fast_wave_tab<ZsaTabLds>(S, ldsTab, S->ring, S->seqStage, S->tags, P, Wn.base, Wn.dictLimit, ip, blockSize, rep, W.seq, &lastLL, fpPosBits, lane);
                 } else if (P.strat == 2) {   // ZSTD_dfast (never with a dictionary here): serial for now, zsa_dfast.h
                     nbSeq = 0;
                     if (lane == 0) nbSeq = zsa_parse_dfast(hashTable, hashTable + (1u << P.hlog), P, Wn.base, Wn.dictLimit, ip, blockSize, rep, W.seq, &lastLL);

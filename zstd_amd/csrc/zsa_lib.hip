@@ -22,9 +22,6 @@
 #ifndef ZSA_ENC_WAVES
 #define ZSA_ENC_WAVES 4       // waves per SIMD the compress kernel is register-budgeted for (16 workgroups per CU)
 #endif
-#define ZSA_SEQ_CAP   (ZSA_BLOCKSIZE_MAX / 4 + 64)          // packed sequences per block (zstd_compress.c:1642-1645)
-#define ZSA_LIT_CAP   (ZSA_BLOCKSIZE_MAX + 128)
-#define ZSA_TMP_CAP   (ZSA_BLOCKSIZE_MAX * 3 / 2 + 512)
 #ifndef ZSA_HT_BYTES
 #define ZSA_HT_BYTES   ((size_t)5 << 20)                     // match table(s) of the frame in flight: 4 << hashLog bytes, plus
                                                             // 4 << chainLog for ZSTD_dfast (level 4 at > 256 KB: 1 MiB + 1 MiB), the
@@ -32,7 +29,23 @@
                                                             // at > 256 KB: 4 MiB + 1 MiB)
 #endif
 #define ZSA_PARK_BYTES ((3 * sizeof(ZsaFseCT) + 255) / 256 * 256)   // sequence tables of the last compressed block (ZSTD_lazy and up)
-#define ZSA_ENC_SCRATCH_BYTES ((size_t)ZSA_SEQ_CAP * 8 + ZSA_LIT_CAP + ZSA_TMP_CAP + ZSA_PARK_BYTES + ZSA_HT_BYTES)
+// Compression workspace of one resident workgroup, sized from the launch: `blockCap` = largest block of the batch (<= 128 KiB),
+// `htBytes` = largest match-table footprint any of its frames needs.  [seq | lit | tmp | park | tables]
+struct ZsaEncLayout { u32 blockCap; u32 litOff, tmpOff, parkOff, htOff; u64 htBytes; u64 stride; };
+static ZsaEncLayout zsa_enc_layout(u64 maxSrcSize, u64 htBytes)
+{
+    ZsaEncLayout L;
+    u64 bc = maxSrcSize < ZSA_BLOCKSIZE_MAX ? (maxSrcSize + 255) / 256 * 256 : ZSA_BLOCKSIZE_MAX;
+    if (bc < 256) bc = 256;
+    L.blockCap = (u32)bc;
+    L.litOff = (u32)((bc / 4 + 64) * 8);
+    L.tmpOff = L.litOff + (u32)bc + 128;
+    L.parkOff = (L.tmpOff + (u32)(bc * 3 / 2) + 512 + 255) / 256 * 256;
+    L.htOff = L.parkOff + (u32)ZSA_PARK_BYTES;
+    L.htBytes = (htBytes + 255) / 256 * 256;
+    L.stride = (u64)L.htOff + L.htBytes;
+    return L;
+}
 #define ZSA_DEC_SCRATCH_BYTES ((size_t)((ZSA_DEC_WKSP_BYTES + 255) / 256 * 256))
 
 struct ZsaLaunchDict { const ZsaCDictDev* cd; const ZsaDDictDev* dd; };
@@ -64,17 +77,19 @@ zsa_k_decompress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ resu
 // ZSTD_dfast and ZSTD_greedy rows there, chosen per frame by its size): each kernel then walks all frames with a counter of
 // its own and takes the ones of its family; `reportUnsupported` says which of the two writes the error word of a frame
 // neither can take (0: not this one, 1: this one, 2: this one, and it is the only launch).
+// FAMILY 2 (zsa_k_compress_lds) keeps the match table of ZSTD_fast frames in LDS (`ldsTab`, ldsTableBytes of dynamic shared
+// memory); a launch that runs it passes the same ldsTableBytes to the FAMILY 0 kernel, which then leaves those frames alone.
 template <int FAMILY>
 ZSA_DEV void zsa_compress_body(ZsaEncShared& S, u32& nextFrame, const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
-                               u32* __restrict__ counter, u8* __restrict__ scratch, int level, const ZsaCDictDev* cd, int reportUnsupported,
-                               u64* __restrict__ prof)
+                               u32* __restrict__ counter, u8* __restrict__ scratch, const ZsaEncLayout L, int level, const ZsaCDictDev* cd,
+                               int reportUnsupported, u64* __restrict__ prof, u32 ldsTableBytes = 0, ZsaTabLds ldsTab = ZsaTabLds())
 {
     if (threadIdx.x == 0) { for (int i = 0; i < ZSA_NPROF; i++) S.prof[i] = 0; S.profLast = wv_clock(); }
-    u8* const wg = scratch + (size_t)blockIdx.x * ZSA_ENC_SCRATCH_BYTES;
+    u8* const wg = scratch + (size_t)blockIdx.x * L.stride;
     ZsaEncScratch W;
-    W.seq = (u64*)wg; W.lit = wg + (size_t)ZSA_SEQ_CAP * 8; W.tmp = W.lit + ZSA_LIT_CAP;
-    W.park = (ZsaFseCT*)(W.tmp + ZSA_TMP_CAP);
-    u32* const zsa_hashTable = (u32*)(W.tmp + ZSA_TMP_CAP + ZSA_PARK_BYTES);
+    W.seq = (u64*)wg; W.lit = wg + L.litOff; W.tmp = wg + L.tmpOff;
+    W.park = (ZsaFseCT*)(wg + L.parkOff);
+    u32* const zsa_hashTable = (u32*)(wg + L.htOff);
     for (;;) {
         if (threadIdx.x == 0) nextFrame = atomicAdd(counter, 1u);
         __syncthreads();
@@ -89,8 +104,20 @@ ZSA_DEV void zsa_compress_body(ZsaEncShared& S, u32& nextFrame, const ZsaFrameDe
                            : zsa_resolveCParams(&cp, level, d.srcSize, 0, zsa_cpm_noAttachDict);
         // strategies: ZSTD_fast, and ZSTD_dfast .. ZSTD_lazy2 without a dictionary; the tables must fit the workgroup's scratch
         size_t const tableBytes = bad ? 0 : ((size_t)4 << cp.hlog) + zsa_auxTableBytes(cp.strat, cp.wlog, cp.hlog, cp.clog);
-        bool const unsupported = bad || !(cp.strat == 1 || (cp.strat >= 2 && cp.strat <= 5 && !cd)) || tableBytes > ZSA_HT_BYTES;
-        if (unsupported) {
+        // (a frame larger than the launch was sized for -- sizes linked on the device -- is refused rather than overrun)
+        bool const unsupported = bad || !(cp.strat == 1 || (cp.strat >= 2 && cp.strat <= 5 && !cd)) || tableBytes > L.htBytes
+                              || (d.srcSize > L.blockCap && L.blockCap < ZSA_BLOCKSIZE_MAX);
+        bool const toLds = !unsupported && !cd && ldsTableBytes && zsa_ldsTableFits(cp.strat, cp.tlen, cp.hlog, d.srcSize, ldsTableBytes);
+        if (FAMILY == 2) {
+            if (toLds) {
+                ZsaEncParams P; P.wlog = cp.wlog; P.hlog = cp.hlog; P.mml = cp.mml; P.tlen = cp.tlen; P.clog = cp.clog; P.strat = cp.strat; P.slog = cp.slog;
+                ZsaTabLds T = ldsTab; T.hi = (u8*)(T.lo + ((size_t)1 << cp.hlog));
+                u64 const r = zsa_encode_frame<2>(&S, zsa_hashTable, P, d.src, d.srcSize, d.dst, d.dstCapacity, W, nullptr, zsa_dm_none, T);
+                if (threadIdx.x == 0) results[f] = r;
+            }
+        } else if (toLds) {
+            // taken by the LDS-table kernel of this launch
+        } else if (unsupported) {
             if (reportUnsupported && threadIdx.x == 0) results[f] = ZSA_ERR(ZSA_parameter_unsupported);
         } else if ((cp.strat >= 3) == (FAMILY == 1)) {
             ZsaEncParams P; P.wlog = cp.wlog; P.hlog = cp.hlog; P.mml = cp.mml; P.tlen = cp.tlen; P.clog = cp.clog; P.strat = cp.strat; P.slog = cp.slog;
@@ -106,25 +133,49 @@ ZSA_DEV void zsa_compress_body(ZsaEncShared& S, u32& nextFrame, const ZsaFrameDe
 
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZSA_ENC_WAVES, ZSA_ENC_WAVES)))
 zsa_k_compress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
-               u32* __restrict__ counter, u8* __restrict__ scratch, int level, const ZsaCDictDev* cd, int reportUnsupported, u64* __restrict__ prof)
+               u32* __restrict__ counter, u8* __restrict__ scratch, const ZsaEncLayout L, int level, const ZsaCDictDev* cd, int reportUnsupported,
+               u64* __restrict__ prof, u32 ldsTableBytes)
 {
     __shared__ ZsaEncShared S;
     __shared__ u32 nextFrame;
-    zsa_compress_body<0>(S, nextFrame, frames, results, nFrames, counter, scratch, level, cd, reportUnsupported, prof);
+    zsa_compress_body<0>(S, nextFrame, frames, results, nFrames, counter, scratch, L, level, cd, reportUnsupported, prof, ldsTableBytes);
+}
+// ZSTD_fast frames (levels 1-2, no dictionary) whose match table fits LDS: ldsTableBytes of dynamic shared memory hold it
+// (24-bit cells, 3 << hashLog bytes), so a CU runs 160 KiB / (table + stage LDS) workgroups and the register budget is wide.
+#ifndef ZSA_LDS_WAVES
+#define ZSA_LDS_WAVES 2
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, ZSA_LDS_WAVES)))
+zsa_k_compress_lds(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
+                   u32* __restrict__ counter, u8* __restrict__ scratch, const ZsaEncLayout L, int level, u64* __restrict__ prof, u32 ldsTableBytes)
+{
+    __shared__ ZsaEncShared S;
+    __shared__ u32 nextFrame;
+    extern __shared__ __align__(16) u8 zsa_dynLds[];
+    ZsaTabLds T; T.lo = (u16*)zsa_dynLds; T.hi = nullptr;
+    zsa_compress_body<2>(S, nextFrame, frames, results, nFrames, counter, scratch, L, level, nullptr, 0, prof, ldsTableBytes, T);
 }
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZSA_ENC_WAVES, ZSA_ENC_WAVES)))
 zsa_k_compress_lazy(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
-                    u32* __restrict__ counter, u8* __restrict__ scratch, int level, const ZsaCDictDev* cd, int reportUnsupported, u64* __restrict__ prof)
+                    u32* __restrict__ counter, u8* __restrict__ scratch, const ZsaEncLayout L, int level, const ZsaCDictDev* cd, int reportUnsupported,
+                    u64* __restrict__ prof)
 {
     __shared__ ZsaEncShared S;
     __shared__ u32 nextFrame;
-    zsa_compress_body<1>(S, nextFrame, frames, results, nFrames, counter, scratch, level, cd, reportUnsupported, prof);
+    zsa_compress_body<1>(S, nextFrame, frames, results, nFrames, counter, scratch, L, level, cd, reportUnsupported, prof);
 }
 
 __global__ void zsa_k_link_sizes(ZsaFrameDesc* __restrict__ frames, const u64* __restrict__ results, u32 n)
 {
     u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { u64 const r = results[i]; frames[i].srcSize = (r > ZSA_ERR(ZSA_maxCode)) ? 0 : r; }
+}
+
+// result words -> int32 (bytes, or -(error code)): the tensor a rank contributes to the all-gather of compressed sizes
+__global__ void zsa_k_export_sizes(const u64* __restrict__ results, s32* __restrict__ out, u32 n)
+{
+    u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { u64 const r = results[i]; out[i] = (r > ZSA_ERR(ZSA_maxCode)) ? -(s32)(u32)((u64)0 - r) : (s32)r; }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -135,15 +186,19 @@ static const size_t kErrGeneric = (size_t)ZSA_ERR(ZSA_GENERIC);
 
 struct zsa_batch_s {
     size_t maxFrames, nFrames;
+    int  device;                 // HIP device the batch and everything it points to live on (checked at every enqueue)
     ZsaFrameDesc* h_frames;      // pinned
     ZsaFrameDesc* d_frames;
     u64* d_results; u64* h_results;   // h_results pinned
     u32* d_counter;
     u8*  d_scratch; size_t scratchBytes;          // decode workspace (literal buffer + parked tables), per resident workgroup
-    u8*  d_encScratch; size_t encScratchBytes;    // compression workspace (sequences, literals, staging, match tables): first compress
+    u8*  d_encScratch; size_t encScratchBytes;    // compression workspace (ZsaEncLayout per resident workgroup): sized by the launches
     size_t wgs;
     int  numCU;
     u64  maxSrcSize;
+    bool sizesOnDevice;          // srcSize words were rewritten on the device (zsa_batch_link_src_sizes): the host copy is stale
+    // what a compress launch at (planLevel, planDict) needs (zsa_plan_compress)
+    int  planLevel; const void* planDict; bool planValid; u32 planLdsBytes; bool planNeedGlobal; u64 planHtBytes;
     unsigned lastWG, lastLDS;
     u64* d_prof; int profOn;
 };
@@ -269,8 +324,9 @@ extern "C" zsa_batch* zsa_batch_create(size_t maxFrames)
     size_t const maxWG = (size_t)b->numCU * ZSA_MAX_WG_PER_CU;
     size_t const wgs = maxFrames < maxWG ? maxFrames : maxWG;
     b->wgs = wgs;
+    b->device = dev;
     b->scratchBytes = wgs * ZSA_DEC_SCRATCH_BYTES;
-    b->encScratchBytes = wgs * ZSA_ENC_SCRATCH_BYTES;   // 5.6 MiB per resident workgroup: allocated by the first compress on this batch
+    b->encScratchBytes = 0;                              // the compression workspace is sized and allocated by the compress launches
     bool ok = hipHostMalloc((void**)&b->h_frames, maxFrames * sizeof(ZsaFrameDesc), hipHostMallocDefault) == hipSuccess
            && hipHostMalloc((void**)&b->h_results, maxFrames * sizeof(u64), hipHostMallocDefault) == hipSuccess
            && hipMalloc((void**)&b->d_frames, maxFrames * sizeof(ZsaFrameDesc)) == hipSuccess
@@ -305,12 +361,14 @@ extern "C" size_t zsa_batch_link_src_sizes(zsa_batch* consumer, const zsa_batch*
     u32 const n = (u32)consumer->nFrames;
     hipLaunchKernelGGL(zsa_k_link_sizes, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, consumer->d_frames, producer->d_results, n);
     HIPCHK(hipGetLastError());
+    consumer->sizesOnDevice = true; consumer->planValid = false;
     return 0;
 }
 extern "C" size_t zsa_batch_upload(zsa_batch* b, size_t nFrames, void* stream)
 {
     if (!b || nFrames > b->maxFrames) return (size_t)ZSA_ERR(ZSA_parameter_outOfBound);
     b->nFrames = nFrames;
+    b->sizesOnDevice = false; b->planValid = false;
     u64 m = 0;
     for (size_t i = 0; i < nFrames; i++) if (b->h_frames[i].srcSize > m) m = b->h_frames[i].srcSize;
     b->maxSrcSize = m;
@@ -327,43 +385,102 @@ static unsigned zsa_grid(const zsa_batch* b, size_t ldsPerWG)
     if (g > b->nFrames) g = b->nFrames;
     return (unsigned)(g ? g : 1);
 }
+// A batch, a dictionary digest and the buffers its frames point to live on one device; a host thread that has switched
+// devices in between (multi-GPU process, a Go thread that migrated) would hand one GPU's pointers to another's kernel.
+static size_t zsa_check_device(const zsa_batch* b, int dictDevice)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) { fprintf(stderr, "libzstd_amd: no usable HIP device -- this library has no CPU path\n"); return kErrGeneric; }
+    if (dev != b->device || (dictDevice >= 0 && dictDevice != b->device)) {
+        fprintf(stderr, "libzstd_amd: device mismatch: current HIP device %d, batch created on %d%s -- refusing to launch\n",
+                dev, b->device, (dictDevice >= 0 && dictDevice != b->device) ? ", dictionary on another device" : "");
+        return (size_t)ZSA_ERR(ZSA_stage_wrong);
+    }
+    return 0;
+}
+
+// What a compress launch of this batch needs: the match-table bytes of its most demanding frame (sizes the workspace),
+// and -- opt-in, see below -- whether the LDS-table kernel takes part.
+#ifndef ZSA_LDS_TABLE_MAX
+#define ZSA_LDS_TABLE_MAX ((size_t)3 << 14)
+#endif
+static void zsa_plan_compress(zsa_batch* b, int level, const zsa_CDict* cdict)
+{
+    if (b->planValid && b->planLevel == level && b->planDict == (const void*)cdict) return;
+    b->planLevel = level; b->planDict = cdict; b->planValid = true; b->planLdsBytes = 0; b->planNeedGlobal = false; b->planHtBytes = 4096;
+    // Measured (profiles/r02_lds_table_*): with the table in LDS a CU holds 4 workgroups instead of 16 and, although each frame
+    // then parses 1.7 x faster and the table traffic is gone, a launch takes 2.3 x longer -- the path is bound by instructions
+    // issued per frame over many resident waves, not by table locality.  The kernel stays as an opt-in experiment.
+    bool const ldsOptIn = getenv("ZSA_LDS_TABLE") != NULL && !cdict;
+    if (b->sizesOnDevice) {   // sizes unknown here: the largest tables the workgroup arena may hold
+        b->planNeedGlobal = true; b->planHtBytes = ZSA_HT_BYTES;
+        if (ldsOptIn && level <= 2) b->planLdsBytes = 3u << 13;
+        return;
+    }
+    for (size_t i = 0; i < b->nFrames; i++) {
+        ZsaCParams cp; int dictMode = zsa_dm_none;
+        u64 const n = b->h_frames[i].srcSize;
+        int const bad = cdict ? zsa_resolveCDictUse(&cp, &dictMode, cdict->cp, cdict->level, cdict->dictSize, n)
+                              : zsa_resolveCParams(&cp, level, n, 0, zsa_cpm_noAttachDict);
+        if (bad) { b->planNeedGlobal = true; continue; }
+        if (ldsOptIn && zsa_ldsTableFits(cp.strat, cp.tlen, cp.hlog, n, ZSA_LDS_TABLE_MAX)) { u32 const t = 3u << cp.hlog; if (t > b->planLdsBytes) b->planLdsBytes = t; continue; }
+        b->planNeedGlobal = true;
+        u64 const t = ((u64)4 << cp.hlog) + zsa_auxTableBytes(cp.strat, cp.wlog, cp.hlog, cp.clog);
+        if (t <= ZSA_HT_BYTES && t > b->planHtBytes) b->planHtBytes = t;   // (larger ones are refused per frame by the kernel)
+    }
+}
 extern "C" size_t zsa_compress_enqueue(zsa_batch* b, int level, const zsa_CDict* cdict, void* stream)
 {
     if (!b) return kErrGeneric;
     if (b->nFrames == 0) return 0;
-    if (!b->d_encScratch) {   // once per batch; every later enqueue allocates nothing
-        if (hipMalloc((void**)&b->d_encScratch, b->encScratchBytes) != hipSuccess) {
-            (void)hipGetLastError();
-            fprintf(stderr, "libzstd_amd: device allocation of the compression workspace failed (%zu bytes)\n", b->encScratchBytes);
-            b->d_encScratch = NULL;
-            return (size_t)ZSA_ERR(ZSA_memory_allocation);
+    { size_t const e = zsa_check_device(b, cdict ? cdict->device : -1); if (e) return e; }
+    zsa_plan_compress(b, level, cdict);
+    ZsaEncLayout const L = zsa_enc_layout(b->sizesOnDevice ? ZSA_BLOCKSIZE_MAX : b->maxSrcSize, b->planHtBytes);
+    size_t const ldsPerWG = sizeof(ZsaEncShared) + 64;
+    unsigned const grid = zsa_grid(b, ldsPerWG);
+    {   // workspace: grows when a launch needs more than the batch has held so far; steady-state enqueues allocate nothing
+        size_t const need = (size_t)grid * L.stride;
+        if (need > b->encScratchBytes) {
+            if (b->d_encScratch) { (void)hipFree(b->d_encScratch); b->d_encScratch = NULL; b->encScratchBytes = 0; }   // (waits for launches using it)
+            if (hipMalloc((void**)&b->d_encScratch, need) != hipSuccess) {
+                (void)hipGetLastError();
+                fprintf(stderr, "libzstd_amd: device allocation of the compression workspace failed (%zu bytes)\n", need);
+                b->d_encScratch = NULL;
+                return (size_t)ZSA_ERR(ZSA_memory_allocation);
+            }
+            b->encScratchBytes = need;
         }
     }
-    size_t const dynLds = 0;
-    size_t const ldsPerWG = sizeof(ZsaEncShared) + 64;
-    static std::once_flag once;
-    std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)zsa_k_compress, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); });
-    unsigned const grid = zsa_grid(b, ldsPerWG);
     HIPCHK(hipMemsetAsync(b->d_counter, 0, 256, (hipStream_t)stream));
     // which parser families the level's clevels.h rows need: ZSTD_fast/ZSTD_dfast up to level 4 (and with a dictionary),
     // ZSTD_greedy/ZSTD_lazy/ZSTD_lazy2 from level 4 on
     bool const fam0 = cdict || level <= 4, fam1 = !cdict && level >= 4;
     const ZsaCDictDev* const cd = cdict ? (const ZsaCDictDev*)cdict->d_cd : (const ZsaCDictDev*)nullptr;
     u64* const prof = b->profOn ? b->d_prof : (u64*)nullptr;
-    if (fam0)
-        hipLaunchKernelGGL(zsa_k_compress, dim3(grid), dim3(64), dynLds, (hipStream_t)stream,
-                           b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter, b->d_encScratch, level, cd, fam1 ? 1 : 2, prof);
+    u32 const ldsBytes = fam0 ? b->planLdsBytes : 0;
+    bool const fam0run = fam0 && (b->planNeedGlobal || fam1 || !ldsBytes);
+    if (ldsBytes) {
+        size_t const ldsWG = ldsPerWG + ldsBytes;
+        unsigned const gridL = zsa_grid(b, ldsWG);
+        hipLaunchKernelGGL(zsa_k_compress_lds, dim3(gridL), dim3(64), ldsBytes, (hipStream_t)stream,
+                           b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter + 32, b->d_encScratch, L, level, prof, ldsBytes);
+        b->lastWG = gridL; b->lastLDS = (unsigned)ldsWG;
+    }
+    if (fam0run)
+        hipLaunchKernelGGL(zsa_k_compress, dim3(grid), dim3(64), 0, (hipStream_t)stream,
+                           b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter, b->d_encScratch, L, level, cd, fam1 ? 1 : 2, prof, ldsBytes);
     if (fam1)   // same scratch: the two launches run one after the other on the stream
-        hipLaunchKernelGGL(zsa_k_compress_lazy, dim3(grid), dim3(64), dynLds, (hipStream_t)stream,
-                           b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter + 16, b->d_encScratch, level, cd, fam0 ? 0 : 2, prof);
+        hipLaunchKernelGGL(zsa_k_compress_lazy, dim3(grid), dim3(64), 0, (hipStream_t)stream,
+                           b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter + 16, b->d_encScratch, L, level, cd, fam0 ? 0 : 2, prof);
     HIPCHK(hipGetLastError());
-    b->lastWG = grid; b->lastLDS = (unsigned)ldsPerWG;
+    if (!ldsBytes) { b->lastWG = grid; b->lastLDS = (unsigned)ldsPerWG; }
     return 0;
 }
 extern "C" size_t zsa_decompress_enqueue(zsa_batch* b, const zsa_DDict* ddict, void* stream)
 {
     if (!b) return kErrGeneric;
     if (b->nFrames == 0) return 0;
+    { size_t const e = zsa_check_device(b, ddict ? ddict->device : -1); if (e) return e; }
     size_t const ldsPerWG = sizeof(ZsaDecShared) + 64;
     unsigned const grid = zsa_grid(b, ldsPerWG);
     HIPCHK(hipMemsetAsync(b->d_counter, 0, 256, (hipStream_t)stream));
@@ -391,31 +508,104 @@ extern "C" size_t zsa_batch_profile(zsa_batch* b, int enable, uint64_t* out /* Z
     return 0;
 }
 extern "C" const uint64_t* zsa_batch_device_results(const zsa_batch* b) { return b ? b->d_results : NULL; }
+extern "C" size_t zsa_batch_export_sizes_i32(const zsa_batch* b, int32_t* d_out, void* stream)
+{
+    if (!b || !d_out) return kErrGeneric;
+    if (b->nFrames == 0) return 0;
+    u32 const n = (u32)b->nFrames;
+    hipLaunchKernelGGL(zsa_k_export_sizes, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->d_results, d_out, n);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 extern "C" void zsa_batch_last_launch(const zsa_batch* b, unsigned* wg, unsigned* lds) { if (b) { if (wg) *wg = b->lastWG; if (lds) *lds = b->lastLDS; } }
 
+// ---- one entry point that allocates nothing (include/zstd_amd.h section 4): the decompress kernel's workspace -- the work
+// counter and, per workgroup, the literal buffer and the parked tables -- lives in a file-scope device array instead of
+// hipMalloc'ed memory.  Each GPU holds its own copy of the array; calls on one GPU share it, so overlapping calls race.
+#define ZSA_NA_WORKGROUPS 128u
+#define ZSA_NA_MAX_FRAMES ((size_t)1 << 20)
+static __device__ __align__(256) u8 zsa_na_scratch[256 + (size_t)ZSA_NA_WORKGROUPS * ZSA_DEC_SCRATCH_BYTES];
+#define ZSA_NA_MAX_DEVICES 64
+static u8* g_naPtr[ZSA_NA_MAX_DEVICES];
+static std::mutex g_naMutex;
+extern "C" size_t zsa_decompress_frames_noalloc(const zsa_frame* d_frames, uint64_t* d_results, size_t nFrames, const zsa_DDict* ddict, void* stream)
+{
+    static_assert(sizeof(zsa_frame) == sizeof(ZsaFrameDesc), "zsa_frame is the kernels' frame descriptor");
+    if (nFrames == 0) return 0;
+    if (!d_frames || !d_results) return kErrGeneric;
+    if (nFrames > ZSA_NA_MAX_FRAMES) {
+        fprintf(stderr, "libzstd_amd: zsa_decompress_frames_noalloc: %zu frames exceed the limit of %zu per call\n", nFrames, ZSA_NA_MAX_FRAMES);
+        return (size_t)ZSA_ERR(ZSA_parameter_outOfBound);
+    }
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ZSA_NA_MAX_DEVICES) { fprintf(stderr, "libzstd_amd: no usable HIP device -- this library has no CPU path\n"); return kErrGeneric; }
+    if (ddict && ddict->device != dev) { fprintf(stderr, "libzstd_amd: device mismatch: dictionary on device %d, current device %d\n", ddict->device, dev); return (size_t)ZSA_ERR(ZSA_stage_wrong); }
+    u8* ptr;
+    {   // the array's address on THIS device, looked up once per device (the name itself is only a host-side handle)
+        std::lock_guard<std::mutex> g(g_naMutex);
+        if (!g_naPtr[dev]) {
+            void* p = nullptr;
+            HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(zsa_na_scratch)));
+            g_naPtr[dev] = (u8*)p;
+        }
+        ptr = g_naPtr[dev];
+    }
+    unsigned const grid = (unsigned)(nFrames < ZSA_NA_WORKGROUPS ? nFrames : ZSA_NA_WORKGROUPS);
+    HIPCHK(hipMemsetAsync(ptr, 0, 256, (hipStream_t)stream));   // the work counter starts at zero; the rest is write-before-read
+    hipLaunchKernelGGL(zsa_k_decompress, dim3(grid), dim3(64), 0, (hipStream_t)stream,
+                       (const ZsaFrameDesc*)d_frames, (u64*)d_results, (u32)nFrames, (u32*)ptr, ptr + 256,
+                       ddict ? (const ZsaDDictDev*)ddict->d_dd : (const ZsaDDictDev*)nullptr, (u64*)nullptr);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // ---- host-memory batches: stage through pinned buffers, run the device batch, copy results back
+// One per calling thread (the reference's call sites are lock-free and may run on any goroutine/OS thread, zstd.go:95-129):
+// sized to the requests the thread has made, released when the thread ends.  At process exit the HIP runtime may already be
+// gone when thread-local destructors run, so from then on everything is left to it.
+static bool g_zsaExiting = false;
+static void zsa_mark_exit() { g_zsaExiting = true; }
 struct ZsaStage {
     u8 *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr;
     size_t inCap = 0, outCap = 0;
     zsa_batch* batch = nullptr;
     hipStream_t stream = nullptr;
     int device = -1;
-    ~ZsaStage() { /* process teardown: leave device memory to the runtime */ }
+    void release()
+    {
+        if (h_in) { (void)hipHostFree(h_in); (void)hipFree(d_in); }
+        if (h_out) { (void)hipHostFree(h_out); (void)hipFree(d_out); }
+        if (batch) zsa_batch_free(batch);
+        if (stream) (void)hipStreamDestroy(stream);
+        h_in = h_out = d_in = d_out = nullptr; inCap = outCap = 0; batch = nullptr; stream = nullptr;
+    }
+    ~ZsaStage()
+    {
+        if (g_zsaExiting || device == -1) return;
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) return;
+        if (cur != device && hipSetDevice(device) != hipSuccess) return;
+        release();
+        if (cur != device) (void)hipSetDevice(cur);
+    }
 };
 static thread_local ZsaStage t_stage;
+// Lets a long-lived thread hand its staging buffers back without ending (no counterpart in libzstd, whose contexts are
+// freed by ZSTD_freeCCtx/ZSTD_freeDCtx: zstd_ctx.go:43-51).
+extern "C" void zsa_thread_release(void) { if (t_stage.device != -1) { t_stage.release(); t_stage.device = -1; } }
 
 static size_t zsa_stage_reserve(ZsaStage& st, size_t inBytes, size_t outBytes, size_t nFrames)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { fprintf(stderr, "libzstd_amd: no usable HIP device -- this library has no CPU path\n"); return kErrGeneric; }
     if (st.device != dev) {   // first use on this thread, or the thread moved to another device: staging is per device
-        if (st.device != -1) {
-            if (st.h_in) { (void)hipHostFree(st.h_in); (void)hipFree(st.d_in); }
-            if (st.h_out) { (void)hipHostFree(st.h_out); (void)hipFree(st.d_out); }
-            if (st.batch) zsa_batch_free(st.batch);
-            if (st.stream) (void)hipStreamDestroy(st.stream);
-            st.h_in = st.h_out = st.d_in = st.d_out = nullptr; st.inCap = st.outCap = 0; st.batch = nullptr; st.stream = nullptr;
+        if (st.device != -1) {   // (what it holds belongs to the old device)
+            int const old = st.device;
+            if (hipSetDevice(old) == hipSuccess) { st.release(); (void)hipSetDevice(dev); }
+            else { st.h_in = st.h_out = st.d_in = st.d_out = nullptr; st.inCap = st.outCap = 0; st.batch = nullptr; st.stream = nullptr; }
         }
+        static std::once_flag once;
+        std::call_once(once, [] { atexit(zsa_mark_exit); });
         HIPCHK(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
         st.device = dev;
     }
@@ -433,8 +623,8 @@ static size_t zsa_stage_reserve(ZsaStage& st, size_t inBytes, size_t outBytes, s
     }
     if (!st.batch || st.batch->maxFrames < nFrames) {
         if (st.batch) zsa_batch_free(st.batch);
-        size_t cap = nFrames < 64 ? 64 : nFrames + (nFrames >> 2);
-        st.batch = zsa_batch_create(cap);
+        size_t const cap = nFrames + (nFrames >> 2);   // sized to the request, geometric growth: a thread that compresses one
+        st.batch = zsa_batch_create(cap);              // payload at a time holds one workgroup's workspace, not a chip's
         if (!st.batch) return kErrMemory;
     }
     return 0;

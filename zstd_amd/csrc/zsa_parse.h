@@ -34,6 +34,9 @@
 #else
 #define ZSA_PPROF(S, lane, slot) do {} while (0)
 #endif
+#ifndef ZSA_STAT          // test builds count how the hoisted window fares (tests/emu)
+#define ZSA_STAT(i) do {} while (0)
+#endif
 struct ZsaEncShared;
 
 struct ZsaRing {
@@ -160,10 +163,31 @@ template <int MLS> ZSA_DEV u32 zsa_hashT(u64 v, u32 hlog)
     return (u32)((v * 0xCF1BBCDCB7A56463ULL) >> (64 - hlog));
 }
 
-// Parses one block.  T: hash table (global, L2-resident).  base: window base (index i <-> base + i, the frame starts at
+// Match-table accessors.  A logical cell is `cellBits` wide: the low posBits bits hold the position, the bits above them a
+// fingerprint of the 4 bytes at that position (or nothing, posBits == 0: plain 32-bit positions as in the reference).
+struct ZsaTabGlobal {   // one 32-bit word per cell in the workgroup's global scratch
+    u32* p;
+    static constexpr u32 cellBits = 32;
+    static constexpr bool lean = false;
+    ZSA_MEM u32 ld(u32 h) const { return p[h]; }
+    ZSA_MEM void st(u32 h, u32 c) const { p[h] = c; }
+    ZSA_MEM u32 ld16(u32) const { return 0; }
+    ZSA_MEM void st16(u32, u32) const {}
+};
+struct ZsaTabLds {      // 24-bit cells in LDS, split into a 16-bit and an 8-bit array: 3 << hashLog bytes per frame
+    u16* lo; u8* hi;
+    static constexpr u32 cellBits = 24;
+    static constexpr bool lean = true;
+    ZSA_MEM u32 ld(u32 h) const { return (u32)lo[h] | ((u32)hi[h] << 16); }
+    ZSA_MEM void st(u32 h, u32 c) const { lo[h] = (u16)c; hi[h] = (u8)(c >> 16); }
+    ZSA_MEM u32 ld16(u32 h) const { return lo[h]; }
+    ZSA_MEM void st16(u32 h, u32 c) const { lo[h] = (u16)c; }
+};
+
+// Parses one block.  T: hash table (global and L2-resident, or LDS).  base: window base (index i <-> base + i, the frame starts at
 // index 2).  Returns the number of sequences appended to seqOut; rep[] and *lastLL are updated.  All values are wave-uniform.
-template <int MLS>
-ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* seqStage, u8* tags, const ZsaEncParams& P, const u8* base, u32 dictLimit,
+template <int MLS, class TAB>
+ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, const TAB T, u32* ringWords, u64* seqStage, u8* tags, const ZsaEncParams& P, const u8* base, u32 dictLimit,
                                  const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL, u32 posBits, int lane)
 {
     u32 const hlog = P.hlog;
@@ -175,10 +199,11 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
     // shows up as a common prefix shorter than 4 and the next event of the window is taken instead).
     bool const useFp = posBits != 0;
     u32 const posMask = useFp ? ((1u << posBits) - 1u) : 0xFFFFFFFFu;
+    u32 const fpShift = 32u - TAB::cellBits + posBits;     // the fingerprint fills the cell bits above the position
 #ifdef ZSA_FP_TEST_BITS   // tests: a few fingerprint bits only, so that collisions are common
-#define ZSA_FPV(x) ((((u32)(x) * 2246822519U) >> posBits) & ((1u << ZSA_FP_TEST_BITS) - 1u))
+#define ZSA_FPV(x) ((((u32)(x) * 2246822519U) >> fpShift) & ((1u << ZSA_FP_TEST_BITS) - 1u))
 #else
-#define ZSA_FPV(x) (((u32)(x) * 2246822519U) >> posBits)
+#define ZSA_FPV(x) (((u32)(x) * 2246822519U) >> fpShift)
 #endif
 #define ZSA_CELL(p, x) (useFp ? ((ZSA_FPV(x) << posBits) | (p)) : (p))
     u32 const stepSize = (P.tlen > 1) ? (P.tlen + 1) : 2;      // zstd_fast.c:153, :429
@@ -212,6 +237,11 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
     // The source words of the first window after a match are requested as soon as the match end is known, so that their
     // LDS round trip overlaps with the post-match table inserts instead of following them.
     u64 vPre = 0; bool havePre = false;
+    // ---- state of the hoisted window (TAB::lean, see the block at the top of the window loop)
+    u32 winB = 0; bool winOK = false;
+    u64 winH = 0, winC = 0;                                 // lanes whose probe is a fingerprint hit / whose cell another lane shares
+    u64 wv64 = 0; u32 whash = 0, wcell = 0, wcand = 0;      // per lane: source word, cell number, own cell value, probed position
+    u32 mOffA = 0, mOffB = 0; u64 mA = 0, mB = 0;           // repcode-compare masks of the window, by offset
     for (;;) {   // one search episode per iteration (label _start)
         u32 step = stepSize, nextStep = ip0 + 128, sNext = stepSize;
         if (ip0 + step + 1 >= ilimit) {
@@ -221,7 +251,7 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
                 { u32 const t = rep2; rep2 = rep1; rep1 = t; }
                 {   u64 const wd = zsa_ring64(R, ip0 - 2);
                     u32 const hh = zsa_hashT<MLS>(wd, hlog);
-                    if (lane == 0) T[hh] = ZSA_CELL(ip0, wd);
+                    if (lane == 0) T.st(hh, ZSA_CELL(ip0, wd));
                     wv_lds_fence();
                 }
                 ip0 += rLength;
@@ -235,8 +265,185 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
         }
         bool blockDone = false;
         for (;;) {   // one window per iteration
+            // the parse state is the same in every lane: keep it in scalar registers (see wv_uniform)
+#ifndef ZSA_NO_UNIFORM_HINT
+            ip0 = wv_uniform(ip0); anchor = wv_uniform(anchor); rep1 = wv_uniform(rep1); rep2 = wv_uniform(rep2);
+            nbSeq = wv_uniform(nbSeq); step = wv_uniform(step); sNext = wv_uniform(sNext); nextStep = wv_uniform(nextStep);
+            chkRep2 = wv_uniform_b(chkRep2); havePre = wv_uniform_b(havePre);
+            R.lo = wv_uniform(R.lo); R.hi = wv_uniform(R.hi);
+            if (TAB::lean) {
+                winB = wv_uniform(winB); winOK = wv_uniform_b(winOK); winH = wv_uniform64(winH); winC = wv_uniform64(winC);
+                mOffA = wv_uniform(mOffA); mOffB = wv_uniform(mOffB); mA = wv_uniform64(mA); mB = wv_uniform64(mB);
+            }
+#endif
             {   u32 const want = ip0 - 2 + 1024;
                 if (R.hi < want && R.hi < R.limit) zsa_ring_fill(R, want, lane);
+            }
+
+            // ---- hoisted window (LDS-resident table).  While the step is 2 every position from ip0 on is visited, so the
+            // per-position work that does not depend on the parse state -- source word, hash, table probe, fingerprint
+            // compare -- is done once for 64 consecutive positions (lane k <-> position winB + k) and reused by every
+            // search that starts inside the window; what remains per sequence is a repcode compare (one mask per offset),
+            // a scalar pick of the first event in the reference's order and the match extension.  The probes stay exact as
+            // long as no cell that two lanes of the window share is written: such lanes are found when the window is set up
+            // (every lane leaves its position in its cell's low half, reads it back, restores it) and a step that would touch
+            // one is left to the general evaluation below, which reads the table afresh.
+            if (TAB::lean && useFp && stepSize == 2 && step == 2 && sNext == 2) {
+                if (!winOK || ip0 - winB > 59u) {
+                    ZSA_STAT(0);
+                    winB = ip0;
+                    u32 const q = winB + (u32)lane;
+                    wv64 = zsa_ring64(R, q - 2);
+                    whash = zsa_hashT<MLS>(wv64, hlog);
+                    u32 const fp = ZSA_FPV(wv64);
+                    wcell = (fp << posBits) | q;
+                    u32 const old = T.ld(whash);
+                    wcand = old & posMask;
+                    winH = wv_ballot(wcand >= prefixStartIndex && (old >> posBits) == fp);
+                    T.st16(whash, q);
+                    wv_lds_fence();
+                    u32 const rb = T.ld16(whash);
+                    wv_lds_fence();
+                    T.st16(whash, old);
+                    wv_lds_fence();
+                    u64 const losers = wv_ballot(rb != (q & 0xFFFFu));
+                    winC = losers;
+                    for (u64 m = losers; m; m &= m - 1) winC |= 1ull << ((wv_readlane(rb, __builtin_ctzll(m)) - winB) & 63u);
+                    mOffA = mOffB = 0; winOK = true;
+                }
+                u32 const o = ip0 - winB;
+                auto repMask = [&](u32 off) -> u64 {   // lanes whose 4 bytes equal the 4 bytes `off` before them
+                    if (off == mOffA) return mA;
+                    if (off == mOffB) return mB;
+                    u32 const q = winB + (u32)lane;
+                    u32 const a = q - 2 - off;
+                    u32 rv = zsa_ring32(R, a);                               // masked ring address, always legal
+                    if (ip0 - 2 - off < R.lo) {                              // uniform: older than the ring
+                        rv = ~(u32)wv64;
+                        if ((u32)lane >= o && q + 4 <= iend) rv = wv_ldg32_now(R.src + a);
+                    }
+                    u64 const m = wv_ballot(rv == (u32)wv64);
+                    mOffB = mOffA; mB = mA; mOffA = off; mA = m;
+                    return m;
+                };
+                if (chkRep2 && ((repMask(rep2) >> o) & 1)) {   // immediate repcode (zstd_fast.c:311-324)
+                    u32 const rLength = zsa_count_wave(R, ip0 + 4 - 2, ip0 + 4 - rep2 - 2, iend - 2, lane) + 4;
+                    { u32 const t = rep2; rep2 = rep1; rep1 = t; }
+                    ZSA_STAT(1);
+                    if ((u32)lane == o) T.st(whash, wcell);
+                    wv_lds_fence();
+                    if ((winC >> o) & 1) winOK = false;
+                    ip0 += rLength;
+                    if (lane == 0) seqStage[nbSeq & 63] = zsa_packseq(0, rLength - ZSA_MINMATCH, 1);
+                    nbSeq++;
+                    if ((nbSeq & 63) == 0) { wv_lds_fence(); seqOut[nbSeq - 64 + (u32)lane] = seqStage[lane]; wv_lds_fence(); }
+                    anchor = ip0;
+                    chkRep2 = (ip0 <= ilimit) && rep2 > 0;
+                    havePre = false;
+                    if (R.hi < ip0 - 2 + 512 && R.hi < R.limit) zsa_ring_fill(R, ip0 - 2 + 1024, lane);
+                    break;   // back to _start with the new ip0
+                }
+                // pairs (ip0 + 2i, ip0 + 2i + 1) that can be decided here: entered by the reference (`ip3 < ilimit`, :328), their
+                // repcode position ip0 + 2i + 2 inside the window, and no step increase before them (:322-327)
+                u32 const iE = (ilimit - ip0 - 2) >> 1;                      // ip0 + 3 < ilimit holds at the top of a window
+                u32 const nCov = (63u - o) >> 1;
+                u32 const room = nextStep - ip0;
+                u32 const nStp = room > 4 ? (room - 3) >> 1 : 0;
+                u32 const n = iE < nCov ? (iE < nStp ? iE : nStp) : (nCov < nStp ? nCov : nStp);
+                if (n) {
+                    u64 const R1 = rep1 ? repMask(rep1) : 0;
+                    u64 const lowH = (1ull << (2 * n)) - 1;                  // n <= 31
+                    u64 Hs = (winH >> o) & lowH;
+                    u64 const Rs = (R1 >> o) & 0x5555555555555554ull & ((lowH << 1) | 1);
+                    u64 const Cs = winC >> o;
+                    ZSA_PPROF(S, lane, 8);
+                    int evRel = -1; u32 evRole = 0, evCand = 0, vFwd = 0, vBwd = 0;
+                    bool bail = false;
+                    for (;;) {
+                        // order of events: the repcode check at ip0 + 2i + 2 precedes the two table checks of pair i
+                        u32 const fh = Hs ? (u32)__builtin_ctzll(Hs) : 64u, fr = Rs ? (u32)__builtin_ctzll(Rs) : 64u;
+                        if (fh == 64 && fr == 64) { bail = (Cs & lowH) != 0; break; }
+                        bool const repWins = fr != 64 && fr <= fh + 2;
+                        u32 const rel = repWins ? fr : fh;
+                        u32 const touched = repWins ? rel : rel + 2;
+                        if (Cs & ((1ull << touched) - 1)) { bail = true; break; }
+                        if (repWins) { evRel = (int)rel; evRole = 0; break; }
+                        u32 const cur = ip0 + rel, m = wv_readlane(wcand, (int)(o + rel));
+                        u32 const mb = (cur - anchor) < (m - prefixStartIndex) ? (cur - anchor) : (m - prefixStartIndex);
+                        zsa_extend_wave(R, cur - 2, m - 2, iend - 2, cur - 2, m - 2, mb, &vFwd, &vBwd, lane);
+                        if (vFwd >= 4) { evRel = (int)rel; evRole = 1 + (rel & 1); evCand = m; break; }
+                        winH &= ~(1ull << (o + rel)); Hs &= ~(1ull << rel);   // fingerprint collision: not an event
+                    }
+                    if (!bail) {
+                        chkRep2 = false; havePre = false;
+                        ZSA_STAT(evRel < 0 ? 2 : 3);
+                        if (evRel < 0) {   // no event: all n pairs enter the table
+                            if ((u32)lane >= o && (u32)lane < o + 2 * n) T.st(whash, wcell);
+                            wv_lds_fence();
+                            if (n == iE) { blockDone = true; break; }
+                            ip0 += 2 * n;
+                            continue;
+                        }
+                        // positions that stay in the table (:266, :278, :300-303): up to the event's pair, plus the next
+                        // pair's first position when the second check hit (step <= 4)
+                        u32 const i2 = evRole == 0 ? (u32)evRel - 2 : ((u32)evRel & ~1u);
+                        u32 const cnt = evRole == 2 ? i2 + 3 : i2 + 2;
+                        if ((u32)lane >= o && (u32)lane < o + cnt) T.st(whash, wcell);
+                        wv_lds_fence();
+                        ZSA_PPROF(S, lane, 9);
+                        u32 current0, match0, mLength, offcode;
+                        if (evRole == 0) {
+                            current0 = ip0 + i2;
+                            ip0 = current0 + 2;
+                            match0 = ip0 - rep1;
+                            offcode = 1;
+                            u32 fwd, bwd;
+                            zsa_extend_wave(R, ip0 + 4 - 2, match0 + 4 - 2, iend - 2, ip0 - 2, match0 - 2, 1, &fwd, &bwd, lane);
+                            ip0 -= bwd; match0 -= bwd;
+                            mLength = 4 + bwd + fwd;
+                        } else {
+                            current0 = ip0 + (u32)evRel;
+                            ip0 = current0;
+                            match0 = evCand;
+                            rep2 = rep1;
+                            rep1 = ip0 - match0;
+                            offcode = rep1 + 3;
+                            ip0 -= vBwd; match0 -= vBwd;
+                            mLength = vBwd + vFwd;
+                        }
+                        if (lane == 0) seqStage[nbSeq & 63] = zsa_packseq(ip0 - anchor, mLength - ZSA_MINMATCH, offcode);
+                        nbSeq++;
+                        if ((nbSeq & 63) == 0) { wv_lds_fence(); seqOut[nbSeq - 64 + (u32)lane] = seqStage[lane]; wv_lds_fence(); }
+                        ip0 += mLength;
+                        anchor = ip0;
+                        if (ip0 <= ilimit) {
+                            if (R.hi < ip0 - 2 + 512 && R.hi < R.limit) zsa_ring_fill(R, ip0 - 2 + 1024, lane);
+                            u32 const pA = current0 + 2, pB = ip0 - 2;   // :307-309, in this order
+                            u32 const lA = pA - winB, lB = pB - winB;
+                            if (lB < 64) {   // both inside the window: their cells are known
+                                if ((u32)lane == lA) T.st(whash, wcell);
+                                wv_lds_fence();
+                                if ((u32)lane == lB) T.st(whash, wcell);
+                                wv_lds_fence();
+                                if (((winC >> lA) | (winC >> lB)) & 1) winOK = false;
+                            } else {
+                                u32 const pp = lane == 0 ? pA : pB;
+                                u32 hh = 0; u64 wd = 0;
+                                if (lane < 2) { wd = RD64(pp); hh = zsa_hashT<MLS>(wd, hlog); }
+                                if (lane == 0) T.st(hh, ZSA_CELL(pp, wd));
+                                wv_lds_fence();
+                                if (lane == 1) T.st(hh, ZSA_CELL(pp, wd));
+                                wv_lds_fence();
+                                winOK = false;
+                            }
+                            chkRep2 = rep2 > 0;
+                        }
+                        ZSA_PPROF(S, lane, 10);
+                        break;   // goto _start
+                    }
+                }
+                ZSA_STAT(n ? 4 : 5);
+                winOK = false;   // the general evaluation below changes the table on its own
             }
             // ---- positions of this window: P_0 = ip0, P_{i+1} = P_i + s_i, s_{i+1} = step at that time (zstd_fast.c:316-327).
             // pos = the position this lane looks at: P_pair (+1) for the hash lanes, P_{pair+1} for the repcode lane.
@@ -269,7 +476,7 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
             havePre = false;
             u32 h = 0, old = 0;
             u32 const myFp = useFp ? ZSA_FPV(v) : 0;
-            if (valid && hashLane) { h = zsa_hashT<MLS>(v, hlog); old = T[h]; tags[h & (ZSA_NTAGS - 1)] = (u8)lane; }
+            if (valid && hashLane) { h = zsa_hashT<MLS>(v, hlog); old = T.ld(h); tags[h & (ZSA_NTAGS - 1)] = (u8)lane; }
             // the repcode-type events (role 0, lane 63) compare real bytes; their read does not depend on the table and
             // shares the gather's round trip
             bool repOK = false;
@@ -309,7 +516,7 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
                 { u32 const t = rep2; rep2 = rep1; rep1 = t; }
                 {   u32 const v63 = wv_readlane((u32)v, 63);
                     u32 const hh = zsa_hashT<MLS>(v63 | ((u64)wv_readlane((u32)(v >> 32), 63) << 32), hlog);
-                    if (lane == 0) T[hh] = ZSA_CELL(ip0, v63);
+                    if (lane == 0) T.st(hh, ZSA_CELL(ip0, v63));
                     wv_lds_fence();
                 }
                 ip0 += rLength;
@@ -350,7 +557,7 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
                         if (s > lane && hs == h) dead = true;
                     }
                 }
-                if (valid && hashLane && !dead) T[h] = ZSA_CELL(pos, v);
+                if (valid && hashLane && !dead) T.st(h, ZSA_CELL(pos, v));
                 wv_lds_fence();
                 if (nv < ZSA_NP || !(endP + endS + 1 < ilimit)) { blockDone = true; break; }
                 ip0 = endP; sNext = endS; step = endC; nextStep = endNext;
@@ -376,10 +583,10 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
                         if (s > lane && hs == h) dead = true;
                     }
                 }
-                if (keep && !dead) T[h] = ZSA_CELL(pos, v);
+                if (keep && !dead) T.st(h, ZSA_CELL(pos, v));
             }
             wv_lds_fence();
-            if (extra && !xInWin) { u64 const vx = RD64(xP); u32 const hx = zsa_hashT<MLS>(vx, hlog); if (lane == 0) T[hx] = ZSA_CELL(xP, vx); wv_lds_fence(); }
+            if (extra && !xInWin) { u64 const vx = RD64(xP); u32 const hx = zsa_hashT<MLS>(vx, hlog); if (lane == 0) T.st(hx, ZSA_CELL(xP, vx)); wv_lds_fence(); }
 
             ZSA_PPROF(S, lane, 9);
             u32 current0, match0, mLength, offcode, maxBack;
@@ -426,7 +633,7 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
                     else { hh = 0; if (lane < 2) { wd = RD64(pp); hh = zsa_hashT<MLS>(wd, hlog); } }
                     // pA then pB: when both fall into one cell only the later one is stored
                     bool const sameCell = wv_readlane(hh, 0) == wv_readlane(hh, 1);
-                    if (lane < 2 && !(lane == 0 && sameCell)) T[hh] = ZSA_CELL(pp, wd);
+                    if (lane < 2 && !(lane == 0 && sameCell)) T.st(hh, ZSA_CELL(pp, wd));
                     wv_lds_fence();
                 }
                 chkRep2 = rep2 > 0;   // :311-324 immediate repcode: evaluated with the next window
@@ -453,13 +660,20 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, u32* T, u32* ringWords, u64* s
     return nbSeq;
 }
 
+template <class TAB>
+ZSA_DEV u32 zsa_parse_fast_wave_tab(ZsaEncShared* S, const TAB T, u32* ringWords, u64* seqStage, u8* tags, const ZsaEncParams& P, const u8* base, u32 dictLimit,
+                                    const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL, u32 posBits, int lane)
+{
+    switch (P.mml) {
+    case 5:  return zsa_parse_fast_waveT<5, TAB>(S, T, ringWords, seqStage, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
+    case 6:  return zsa_parse_fast_waveT<6, TAB>(S, T, ringWords, seqStage, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
+    case 7:  return zsa_parse_fast_waveT<7, TAB>(S, T, ringWords, seqStage, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
+    default: return zsa_parse_fast_waveT<4, TAB>(S, T, ringWords, seqStage, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
+    }
+}
 ZSA_DEV u32 zsa_parse_fast_wave(ZsaEncShared* S, u32* T, u32* ringWords, u64* seqStage, u8* tags, const ZsaEncParams& P, const u8* base, u32 dictLimit,
                                 const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL, u32 posBits, int lane)
 {
-    switch (P.mml) {
-    case 5:  return zsa_parse_fast_waveT<5>(S, T, ringWords, seqStage, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
-    case 6:  return zsa_parse_fast_waveT<6>(S, T, ringWords, seqStage, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
-    case 7:  return zsa_parse_fast_waveT<7>(S, T, ringWords, seqStage, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
-    default: return zsa_parse_fast_waveT<4>(S, T, ringWords, seqStage, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
-    }
+    ZsaTabGlobal tab; tab.p = T;
+    return zsa_parse_fast_wave_tab<ZsaTabGlobal>(S, tab, ringWords, seqStage, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
 }

@@ -6,6 +6,7 @@
 
 #define ZSA_DEV    __device__ __forceinline__
 #define ZSA_DEVFN  __device__ __noinline__
+#define ZSA_MEM    __device__ __forceinline__      // member functions
 #define ZSA_HD     __host__ __device__ inline
 #define ZSA_SHARED __shared__
 #define ZSA_WAVE   64
@@ -23,6 +24,13 @@ ZSA_DEV void wv_sync() { __syncthreads(); }
 ZSA_DEV void wv_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 // value of `v` in lane `srcLane`; srcLane must be wave-uniform
 ZSA_DEV unsigned wv_readlane(unsigned v, int srcLane) { return (unsigned)__builtin_amdgcn_readlane((int)v, srcLane); }
+// Tells the compiler that `v` holds the same value in every lane (it cannot always prove it: a value that once passed through
+// per-lane control flow stays "divergent" for it, and a divergent parse position turns every branch of the parse loop into
+// exec-mask bookkeeping).  The result lives in a scalar register; everything computed from it is scalar work.
+ZSA_DEV unsigned wv_uniform(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+ZSA_DEV unsigned long long wv_uniform64(unsigned long long v)
+{ return (unsigned long long)wv_uniform((unsigned)v) | ((unsigned long long)wv_uniform((unsigned)(v >> 32)) << 32); }
+ZSA_DEV bool wv_uniform_b(bool v) { return wv_uniform(v ? 1u : 0u) != 0; }
 // bytes [sh, sh+4) of the little-endian 8-byte value hi:lo, sh in 0..3
 ZSA_DEV unsigned wv_alignbyte(unsigned hi, unsigned lo, unsigned sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
 // loads from a pointer known to be global memory (frame descriptors hand out generic pointers: without this the compiler
