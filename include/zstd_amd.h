@@ -68,8 +68,13 @@ size_t zsa_decompress_batch(const void* const* src, const size_t* srcSize, void*
  * 3. Batch entry points, device memory -- inputs and outputs already resident in HBM (what bench.py times).
  *    A zsa_batch owns everything a launch needs (frame table, result words, per-workgroup scratch), so
  *    zsa_*_enqueue only put work on `stream` (a hipStream_t passed as void*; NULL = the default stream) and allocate
- *    nothing -- except the first zsa_compress_enqueue on a batch, which allocates that batch's compression workspace
- *    once (5.6 MiB per resident workgroup).  All device pointers must belong to the current HIP device.
+ *    nothing -- except a zsa_compress_enqueue that needs a larger compression workspace than the batch holds so far
+ *    (normally only the first: the workspace is sized from the launch -- largest block and largest match tables of its
+ *    frames, e.g. 0.6 MiB per resident workgroup for 128 KiB level-1 frames).  A batch, the dictionaries used with it and
+ *    all device pointers must belong to the HIP device that was current at zsa_batch_create; an enqueue made under
+ *    another device returns "Operation not authorized at current processing stage".
+ *    Capacity contract (all compress entry points): dstCapacity >= zsa_compressBound(srcSize) -- what every reference
+ *    call site passes (zstd.go:96-101) -- else "Destination buffer is too small", even where the frame would have fit.
  * ------------------------------------------------------------------------------------------------------- */
 typedef struct zsa_batch_s zsa_batch;
 zsa_batch* zsa_batch_create(size_t maxFrames);
@@ -92,12 +97,35 @@ size_t zsa_decompress_enqueue(zsa_batch* b, const zsa_DDict* ddict, void* stream
 size_t zsa_batch_results(zsa_batch* b, size_t* outSize, void* stream);
 /* device pointer to the per-frame result words (uint64), for consumers that stay on the GPU */
 const uint64_t* zsa_batch_device_results(const zsa_batch* b);
+/* on the device: result words -> int32 (bytes written, or -(error code)) into d_out[0..nFrames): the tensor a rank hands to
+ * the all-gather of compressed sizes that gives every rank the global output offsets (no reference counterpart:
+ * the reference's callers fan out over goroutines, zstd_stream_test.go:149-169) */
+size_t zsa_batch_export_sizes_i32(const zsa_batch* b, int32_t* d_out, void* stream);
 /* geometry of the last launch (for roofline bookkeeping): workgroups launched, LDS bytes per workgroup */
 void zsa_batch_last_launch(const zsa_batch* b, unsigned* workgroups, unsigned* ldsBytes);
 
 /* diagnostics: enable/disable per-phase cycle accounting for launches of this batch; when `out` is non-NULL it first
  * receives the 12 accumulated counters (shader-clock cycles of lane 0, summed over workgroups). */
 size_t zsa_batch_profile(zsa_batch* b, int enable, uint64_t* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * 4. One entry point that allocates nothing.  No counterpart in the reference: it is for callers that cannot call
+ *    hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation.
+ *    Decompresses nFrames frames described by a DEVICE array of zsa_frame (device pointers inside), writing one
+ *    result word per frame (bytes or (uint64)-error, as zsa_batch_device_results) to d_results.  Same kernel as
+ *    zsa_decompress_enqueue; its workspace (work counter, per-workgroup literal buffer and parked tables) is a
+ *    19 MB array inside the library's code object instead of batch-owned memory, each GPU holding its own copy.
+ *    Limits: at most 2^20 frames per call (more: "Parameter is out of bound"); 128 resident workgroups, so throughput
+ *    is below a zsa_batch's.  Calls on one GPU share that array: calls that overlap on one GPU race -- serialise them
+ *    (one stream, or events).  The launch is asynchronous on `stream`.
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct { const void* src; void* dst; uint64_t srcSize; uint64_t dstCapacity; } zsa_frame;
+size_t zsa_decompress_frames_noalloc(const zsa_frame* d_frames, uint64_t* d_results, size_t nFrames,
+                                     const zsa_DDict* ddict /* or NULL */, void* stream);
+
+/* staging buffers of the single-call / host-batch entry points are per calling thread and released when the thread ends;
+ * a long-lived thread can hand them back early.  (libzstd: ZSTD_freeCCtx / ZSTD_freeDCtx, zstd_ctx.go:43-51) */
+void zsa_thread_release(void);
 
 /* resolved compression parameters {windowLog, chainLog, hashLog, searchLog, minMatch, targetLength, strategy}
  * for (level, srcSize, dictSize); mirrors ZSTD_getCParams_internal (zstd_compress.c:6960-6983) for the rows this
