@@ -1,20 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the level-1 batch codec (BASELINE.json configs[1]).
+"""bench.py -- headline benchmark of the batch codec (BASELINE.json configs[1]).
 
 Workload per GPU: 1 GiB fixed-seed synthetic log corpus cut into 8192 independent 128 KiB frames (weak scaling:
 every rank gets its own 8192 frames of the same corpus family).  A "step" is one pass of the hot path over the
-batch: compress all frames at level 1, then decompress what was just produced -- inputs, outputs and all
-intermediate sizes stay in HBM (the compressed sizes are handed from the compress kernel to the decompress
-launch on the device).
+batch: compress all frames, hand the compressed sizes over on the device, decompress what was just produced --
+inputs, outputs and all intermediate sizes stay in HBM.  With more than one rank the step also contains the path's
+only exchange: an all-gather of the per-frame compressed sizes (taken from the kernel's result words on the device)
+from which every rank derives the global output offsets.
 
-Prints ONE JSON line on rank 0 (see the contract in the task description): `value` is GB/s of UNCOMPRESSED
-bytes through the full compress+decompress round trip, whole job; per-direction rates, ratio, roofline of the
-dominant kernel and the CPU baseline ride along in the same object.
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts N ranks itself (torch.distributed.run,
+one process per GPU) before anything touches a GPU, and fails loudly when the box has fewer devices.
+
+Prints ONE JSON line on rank 0: `value` is GB/s of UNCOMPRESSED bytes through the full compress+decompress round
+trip, whole job; per-direction rates, ratio, roofline of the dominant kernel, the PCIe-inclusive host-batch rate and
+the CPU baseline ride along in the same object.
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
+import socket
 import subprocess
 import sys
 import time
@@ -32,7 +38,8 @@ def shard_plan(n_frames_per_rank, rank, world):
 
 def global_offsets(sizes_per_rank):
     """Exclusive prefix sum over the rank-major concatenation of per-frame compressed sizes: what every rank can
-    compute after the single all-gather of sizes (the only exchange step of the path)."""
+    compute after the single all-gather of sizes (the only exchange step of the path).  Host restatement of
+    exchange_sizes(), used by the tests."""
     out, acc = [], 0
     for sizes in sizes_per_rank:
         row = []
@@ -43,9 +50,84 @@ def global_offsets(sizes_per_rank):
     return out, acc
 
 
+def exchange_sizes(sizes, world):
+    """The exchange step: `sizes` (int32 tensor, this rank's per-frame compressed sizes, on the device the backend
+    works on) -> (gathered [world, n] int32, offsets [world * n] int64 exclusive prefix sum, total).  One collective."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        flat_out = torch.empty(world * sizes.numel(), dtype=sizes.dtype, device=sizes.device)
+        dist.all_gather_into_tensor(flat_out, sizes)
+        gathered = flat_out.view(world, -1)
+    else:
+        gathered = sizes.view(1, -1)
+    flat = gathered.reshape(-1).to(torch.int64)
+    incl = torch.cumsum(flat, 0)
+    return gathered, incl - flat, incl[-1]
+
+
+def ranks_agree(offsets, world):
+    """True when every rank derived the same offsets (checked with one MIN and one MAX reduction of a digest)."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return True
+    w = torch.arange(1, offsets.numel() + 1, dtype=torch.int64, device=offsets.device)
+    digest = ((offsets * w) % 1000003).sum().reshape(1)
+    lo, hi = digest.clone(), digest.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return bool((lo == hi).item())
+
+
+def spawn_ranks(n, argv, need_gpus=True):
+    """Start n ranks of this script under torch.distributed.run and exit with their status.  Called before any GPU
+    call of this process (torch.cuda.device_count() does not initialise the GPU on this image)."""
+    if need_gpus:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d asked for, but this box has %d GPU(s); not running a smaller job under that name\n" % (n, have))
+            sys.exit(3)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    sys.exit(subprocess.call(cmd))
+
+
+def build_id():
+    """Digest of the engine's sources: ties a committed PMC summary to the build being timed."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "zstd_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_run(exe, lib, impl, frame_size, frames, seed, threads, level):
+    out = subprocess.run([exe, lib, impl, "0", str(frame_size), str(frames), str(seed), str(threads), str(level)],
+                         capture_output=True, text=True, timeout=600, check=True).stdout
+    return json.loads(out.strip().splitlines()[-1])
+
+
 def cpu_baseline(frame_size, n_frames, seed, level):
     """Reference C path (oracle/_ref, libzstd 1.5.5 as vendored by the reference) on the host cores of this box,
-    one ZSTD_compress/ZSTD_decompress call per frame from a pthread pool (Go is not installed)."""
+    one ZSTD_compress/ZSTD_decompress call per frame from a pthread pool over all the frames of the workload
+    (Go is not installed).  Threads = every core this process may run on; the 1-thread figure (on a
+    quarter of the frames) and, where it differs, the figure at the box's CPU share (OMP_NUM_THREADS) ride along."""
     exe = os.path.join(ROOT, "oracle", "_ref", "cpu_bench")
     lib = os.path.join(ROOT, "oracle", "_ref", "libzstd_ref.so")
     kind, impl = "reference", "ref"
@@ -58,20 +140,77 @@ def cpu_baseline(frame_size, n_frames, seed, level):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", "16")), 64))
-    sample = min(n_frames, 4096)
+    cores = max(1, min(cores, 256))          # (cpu_bench's thread table)
     try:
-        out = subprocess.run([exe, lib, impl, "0", str(frame_size), str(sample), str(seed), str(cores), str(level)],
-                             capture_output=True, text=True, timeout=240, check=True).stdout
-        r = json.loads(out.strip().splitlines()[-1])
+        share = max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", str(cores)))))
+    except ValueError:
+        share = cores
+
+    def fold(r):
+        tc, td = 1.0 / r["compress_GBps"], 1.0 / r["decompress_GBps"]
+        return {"round_trip_GBps": round(1.0 / (tc + td), 4), "compress_GBps": r["compress_GBps"], "decompress_GBps": r["decompress_GBps"]}
+    try:
+        full = _cpu_run(exe, lib, impl, frame_size, n_frames, seed, cores, level)
+        res = {"value": fold(full)["round_trip_GBps"], "unit": "GB/s", "cores": cores, "kind": kind, "cpu_model": cpu_model(),
+               "compress_GBps": full["compress_GBps"], "decompress_GBps": full["decompress_GBps"], "ratio": full["ratio"],
+               "libzstd": full["libzstd"],
+               "sample": "all %d frames (%d KiB each, same corpus/seed), %d pthreads = every core in sched_getaffinity, one call per frame"
+                         % (n_frames, frame_size // 1024, cores)}
+        one = _cpu_run(exe, lib, impl, frame_size, max(1, n_frames // 4), seed, 1, level)
+        res["one_thread"] = dict(fold(one), frames=max(1, n_frames // 4))
+        if share != cores:
+            sh = _cpu_run(exe, lib, impl, frame_size, n_frames, seed, share, level)
+            res["at_cpu_share"] = dict(fold(sh), threads=share, note="OMP_NUM_THREADS: the CPU share the harness gives one GPU's job")
+        return res
     except Exception as e:   # the baseline is a reported number, never a reason to lose the GPU line
         return {"value": None, "unit": "GB/s", "cores": cores, "kind": kind, "sample": "failed: %r" % (e,)}
-    tc, td = 1.0 / r["compress_GBps"], 1.0 / r["decompress_GBps"]
-    return {"value": round(1.0 / (tc + td), 4), "unit": "GB/s", "cores": cores, "kind": kind,
-            "compress_GBps": r["compress_GBps"], "decompress_GBps": r["decompress_GBps"], "ratio": r["ratio"],
-            "libzstd": r["libzstd"],
-            "sample": "%d of the %d frames (%d KiB each, same corpus/seed), %d pthreads, one call per frame"
-                      % (sample, n_frames, frame_size // 1024, cores)}
+
+
+def end_to_end(zstd_amd, host, frame_size, n, level):
+    """PCIe-inclusive rate: the host-buffer entry points (zsa_compress_batch / zsa_decompress_batch) on a bounded
+    sample of the same frames -- pageable host memory in, pageable host memory out.  Reported beside `value`, never
+    instead of it."""
+    import numpy as np
+    from zstd_amd._lib import lib, c_size_p, c_void_pp
+    bound = zstd_amd.CompressBound(frame_size)
+    cbuf = np.empty(n * bound, dtype=np.uint8)
+    back = np.empty(n * frame_size, dtype=np.uint8)
+    P, S = ctypes.c_void_p * n, ctypes.c_size_t * n
+    srcp = P(*[host.ctypes.data + i * frame_size for i in range(n)])
+    srcn = S(*([frame_size] * n))
+    dstp = P(*[cbuf.ctypes.data + i * bound for i in range(n)])
+    dstc = S(*([bound] * n))
+    outn = S()
+    cast = lambda a, t: ctypes.cast(a, t)
+    best_c = best_d = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        rc = lib.zsa_compress_batch(cast(srcp, c_void_pp), cast(srcn, c_size_p), cast(dstp, c_void_pp), cast(dstc, c_size_p), cast(outn, c_size_p), n, level, None)
+        best_c = min(best_c, time.perf_counter() - t0)
+        assert rc == 0
+    csz = [outn[i] for i in range(n)]
+    assert all(c < 2 ** 63 for c in csz)
+    backp = P(*[back.ctypes.data + i * frame_size for i in range(n)])
+    cszA = S(*csz)
+    outd = S()
+    for _ in range(3):
+        t0 = time.perf_counter()
+        rc = lib.zsa_decompress_batch(cast(dstp, c_void_pp), cast(cszA, c_size_p), cast(backp, c_void_pp), cast(srcn, c_size_p), cast(outd, c_size_p), n, None)
+        best_d = min(best_d, time.perf_counter() - t0)
+        assert rc == 0
+    assert bool((back == host[:n * frame_size]).all()), "host-batch round trip is not bit-exact"
+    # single-call latency (zstd_bullk_test.go:252 quotes 1.5 us/op for the CPU library on a 92-byte payload)
+    small = bytes(host[:1024])
+    zstd_amd.CompressLevel(None, small, level)
+    t0 = time.perf_counter()
+    for _ in range(200):
+        zstd_amd.CompressLevel(None, small, level)
+    single_us = (time.perf_counter() - t0) / 200 * 1e6
+    b = float(n) * frame_size
+    return {"compress_GBps": round(b / best_c / 1e9, 3), "decompress_GBps": round(b / best_d / 1e9, 3),
+            "round_trip_GBps": round(b / (best_c + best_d) / 1e9, 3),
+            "sample": "%d of the frames through zsa_compress_batch / zsa_decompress_batch, pageable host buffers, best of 3" % n,
+            "single_call_compress_us_1KiB": round(single_us, 1)}
 
 
 def main():
@@ -84,20 +223,56 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--level", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--exchange-dry-run", action="store_true",
+                    help="CPU-only rehearsal of the rank plumbing (spawn, shard plan, all-gather of sizes, offsets) over gloo with "
+                         "made-up sizes; nothing is compressed and no throughput is printed")
     args = ap.parse_args()
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        spawn_ranks(args.gpus, sys.argv[1:], need_gpus=not args.exchange_dry_run)      # does not return
+    world = int(env_world or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; launch one rank per GPU (or let bench.py start them: unset WORLD_SIZE)\n" % (args.gpus, world))
+        sys.exit(3)
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.exchange_dry_run:
+        if world > 1:
+            dist.init_process_group("gloo")
+        first, count = shard_plan(args.frames, rank, world)
+        g = torch.Generator().manual_seed(args.seed)
+        all_sizes = torch.randint(1000, 40000, (world * args.frames,), generator=g, dtype=torch.int32)   # same on every rank
+        mine = all_sizes[first:first + count].clone()
+        gathered, offsets, total = exchange_sizes(mine, world)
+        ok = bool(torch.equal(gathered.reshape(-1), all_sizes)) and ranks_agree(offsets, world)
+        want, want_total = global_offsets([all_sizes[r * args.frames:(r + 1) * args.frames].tolist() for r in range(world)])
+        ok = ok and offsets.tolist() == [o for row in want for o in row] and int(total) == want_total
+        if world > 1:
+            flag = torch.tensor([1 if ok else 0])
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(flag.item())
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"exchange_dry_run": True, "n_ranks": world, "frames_per_rank": args.frames, "offsets_agree": ok,
+                              "total_bytes": int(total)}), flush=True)
+        sys.exit(0 if ok else 1)
+
     assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU path)"
+    if torch.cuda.device_count() <= local_rank:
+        sys.stderr.write("bench.py: rank %d has no GPU (device_count %d)\n" % (local_rank, torch.cuda.device_count()))
+        sys.exit(3)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
+        world = dist.get_world_size()
 
     import zstd_amd
     from zstd_amd import corpus
@@ -110,6 +285,7 @@ def main():
     stride = (bound + 255) // 256 * 256
     cbuf = torch.empty(N * stride, dtype=torch.uint8, device=dev)
     out = torch.empty(N * FS, dtype=torch.uint8, device=dev)
+    sizes_dev = torch.zeros(N, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
     enc = zstd_amd.DeviceBatch(N)
@@ -118,16 +294,19 @@ def main():
     dec.set_frames_strided(N, cbuf.data_ptr(), stride, None, out.data_ptr(), FS, FS, stream)
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    sizes_dev = None
+    last = {}
 
-    def step(timed):
-        """one pass: compress -> (device-side hand-over of sizes) -> decompress; HIP events on the launch stream"""
+    def step():
+        """one pass: compress -> (device-side hand-over of sizes) -> decompress -> exchange of sizes; HIP events on the
+        launch stream (torch's current stream, which is also the stream the collective is enqueued on)"""
         ev[0].record()
         enc.compress(args.level, None, stream)
         ev[1].record()
         dec.link_src_sizes(enc, stream)
         dec.decompress(None, stream)
         ev[2].record()
+        enc.export_sizes_i32(sizes_dev.data_ptr(), stream)
+        last["gathered"], last["offsets"], last["total"] = exchange_sizes(sizes_dev, world)
 
     def barrier():
         if world > 1:
@@ -135,7 +314,9 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step(False)
+        step()
+    if not args.warmup:
+        step()
     torch.cuda.synchronize()
 
     # correctness gate (outside the timed region): every frame compressed, decoded, and bit-exact
@@ -144,6 +325,8 @@ def main():
     assert all(c < 2 ** 63 for c in csizes), "compress errors: %s" % [zstd_amd.ErrorCode(c - 2 ** 64) for c in csizes if c >= 2 ** 63][:3]
     assert all(d == FS for d in dsizes), "decompress errors"
     assert bool(torch.equal(out, src)), "round trip is not bit-exact"
+    assert last["gathered"][rank].tolist() == csizes, "the exchanged sizes are not the kernel's result words"
+    assert ranks_agree(last["offsets"], world), "ranks disagree on the global output offsets"
     identical = None
     if rank == 0:
         opath = os.path.join(ROOT, "oracle", "liboracle.so")
@@ -165,26 +348,17 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(True)
-        if world > 1:   # the path's only exchange: all ranks learn all compressed sizes (global output offsets)
-            if sizes_dev is None:
-                sizes_dev = torch.tensor(csizes, dtype=torch.int32, device=dev)
-                gathered = [torch.empty_like(sizes_dev) for _ in range(world)]
-            dist.all_gather(gathered, sizes_dev)
+        step()
         ev[2].synchronize()
         t_c += ev[0].elapsed_time(ev[1])
         t_d += ev[1].elapsed_time(ev[2])
     barrier()
     elapsed = time.perf_counter() - t0
+    total_c_all = float(last["total"].item())
     if world > 1:
         t = torch.tensor([elapsed, t_c, t_d], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, t_c, t_d = [float(x) for x in t.tolist()]
-        tot = torch.tensor([total_c], dtype=torch.float64, device=dev)
-        dist.all_reduce(tot)
-        total_c_all = float(tot.item())
-    else:
-        total_c_all = float(total_c)
 
     if rank == 0:
         K = args.steps
@@ -195,9 +369,12 @@ def main():
         algo_c = bytes_rank + float(total_c)      # compress = srcSize + cSize per frame
         algo_d = float(total_c) + bytes_rank      #              decompress = cSize + dstSize
         wg, lds = enc.last_launch()
-        traffic_c, traffic_d, traffic_src = committed_traffic(N, FS, args.level)
+        kernel_c = "zsa_k_compress" if args.level < 4 else "zsa_k_compress_lazy" if args.level > 4 else "zsa_k_compress + zsa_k_compress_lazy"
+        if os.environ.get("ZSA_LDS_TABLE") and args.level <= 2:
+            kernel_c = "zsa_k_compress_lds"
+        traffic_c, traffic_d, traffic_src = committed_traffic(N, FS, args.level, kernel_c)
         res = {
-            "metric": "GB/s compress & decompress round trip (whole job, uncompressed bytes), 128 KiB frames, level 1; ratio",
+            "metric": "GB/s compress & decompress round trip (whole job, uncompressed bytes), %d KiB frames, level %d; ratio" % (FS // 1024, args.level),
             "value": round(bytes_all / elapsed * K / 1e9, 3),
             "unit": "GB/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -206,13 +383,16 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%d x %d KiB independent level-%d frames per GPU, fixed-seed log-like corpus (seed %d), compress then decompress, device resident"
                                    % (N, FS // 1024, args.level, args.seed),
-                       "frames_per_gpu": N, "frame_bytes": FS, "level": args.level, "parallelism": "batch split x%d" % world},
+                       "frames_per_gpu": N, "frame_bytes": FS, "level": args.level, "parallelism": "batch split x%d" % world,
+                       "exchange": "all-gather of per-frame compressed sizes (int32 x %d per rank) every step" % N if world > 1 else "none (one rank)"},
             "compress_GBps": round(bytes_all / (kc_ms / 1e3) / 1e9, 3),
             "decompress_GBps": round(bytes_all / (kd_ms / 1e3) / 1e9, 3),
             "ratio": round(bytes_all / total_c_all, 4),
             "bit_exact_round_trip": True,
             "byte_identical_to_oracle_sample": identical,
-            "roofline": {"bound": "hbm", "kernel": "zsa_k_compress", "achieved": round(algo_c / (kc_ms / 1e3) / 1e9, 3),
+            "global_offsets_agree_on_all_ranks": True,
+            "build_id": build_id(),
+            "roofline": {"bound": "hbm", "kernel": kernel_c, "achieved": round(algo_c / (kc_ms / 1e3) / 1e9, 3),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(algo_c / (kc_ms / 1e3) / 1e9 / HBM_PEAK_GBPS, 6),
                          "traffic": traffic_c, "traffic_source": traffic_src, "avg_launch_ms": round(kc_ms, 3), "algorithmic_bytes_per_launch": int(algo_c),
                          "workgroups": wg, "lds_bytes_per_workgroup": lds},
@@ -220,26 +400,38 @@ def main():
                                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(algo_d / (kd_ms / 1e3) / 1e9 / HBM_PEAK_GBPS, 6),
                                     "traffic": traffic_d, "avg_launch_ms": round(kd_ms, 3), "algorithmic_bytes_per_launch": int(algo_d)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_end_to_end:
+            try:
+                res["end_to_end"] = end_to_end(zstd_amd, host, FS, min(N, 2048), args.level)
+            except Exception as e:   # a reported extra, never a reason to lose the line
+                res["end_to_end"] = {"failed": repr(e)}
+        if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(FS, N, args.seed, args.level)
         print(json.dumps(res), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
 # HBM bytes per launch need PMC passes of their own (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE cannot ride along with a
 # timed run); tools/collect_profiles.sh runs them on this very command and tools/summarize_profiles.py commits the
-# per-launch averages, with the guide's gfx950 correction (FETCH_SIZE counts 128-B requests as 64 B: x2), to this file.
-PMC_SUMMARY = "profiles/r01_v10_pmc.json"
+# per-launch averages, with the guide's gfx950 correction (FETCH_SIZE counts 128-B requests as 64 B: x2), to this file,
+# stamped with build_id().  A summary taken on another build, workload or kernel is not quoted: traffic is null then.
+PMC_SUMMARY = "profiles/r02_pmc.json"
 
 
-def committed_traffic(n_frames, frame_bytes, level):
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_SUMMARY)
-    if not (os.path.exists(path) and n_frames == 8192 and frame_bytes == 131072 and level == 1):
-        return None, None, None      # the summary was taken on the default workload only
+def committed_traffic(n_frames, frame_bytes, level, kernel_c):
+    path = os.path.join(ROOT, PMC_SUMMARY)
+    if not os.path.exists(path):
+        return None, None, "no PMC summary committed (%s)" % PMC_SUMMARY
     pmc = json.load(open(path))
+    if pmc.get("build_id") != build_id():
+        return None, None, "%s was collected on build %s, this is build %s: re-run tools/collect_profiles.sh" % (PMC_SUMMARY, pmc.get("build_id"), build_id())
+    w = pmc.get("workload", {})
+    if (w.get("frames"), w.get("frame_bytes"), w.get("level")) != (n_frames, frame_bytes, level):
+        return None, None, "%s was collected on another workload" % PMC_SUMMARY
     get = lambda k: (int(pmc[k]["hbm_traffic_bytes"]) if k in pmc and "hbm_traffic_bytes" in pmc[k] else None)
-    return get("zsa_k_compress"), get("zsa_k_decompress"), PMC_SUMMARY + " (separate rocprofv3 --pmc passes of this command, per launch)"
+    return get(kernel_c), get("zsa_k_decompress"), PMC_SUMMARY + " (separate rocprofv3 --pmc passes of this command and build, per launch)"
 
 
 if __name__ == "__main__":

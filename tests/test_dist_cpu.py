@@ -51,3 +51,36 @@ def test_two_rank_split_and_offsets():
     # the split corpus equals the unsplit one
     from zstd_amd import corpus
     assert corpus.frames("log", 16384, 12, 42) == corpus.frames("log", 16384, 6, 42) + corpus.frames("log", 16384, 6, 42, first_frame=6)
+
+
+def _bench(*args, timeout=240):
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_bench_spawns_ranks_itself():
+    """`bench.py --gpus 2` without WORLD_SIZE starts two ranks through torch.distributed.run (the entry the driver's
+    N-GPU runs take); rehearsed here over gloo with made-up sizes: shard plan, all-gather of sizes, global offsets equal
+    on both ranks and equal to the host restatement."""
+    import json
+    r = _bench("--gpus", "2", "--exchange-dry-run", "--frames", "257")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_ranks"] == 2 and d["offsets_agree"] is True and d["frames_per_rank"] == 257
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    """asking for more GPUs than exist must fail loudly, never run a smaller job under the larger name"""
+    import torch
+    have = torch.cuda.device_count()
+    r = _bench("--gpus", str(have + 2), "--steps", "1", "--warmup", "0")
+    assert r.returncode != 0 and "GPU(s)" in r.stderr and not any(l.startswith('{"metric"') for l in r.stdout.splitlines())
+    # a rank count that contradicts --gpus is refused as well
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr

@@ -17,9 +17,10 @@ def find(d, suffix):
 ks = find(tag + "_trace", "kernel_stats.csv")
 if ks:
     shutil.copy(ks, os.path.join(dst, tag + "_kernel_stats.csv"))
-for line in open(os.path.join(src, tag + "_trace.log"), errors="replace"):
-    if line.startswith('{"metric"'):
-        open(os.path.join(dst, tag + "_bench_under_trace.json"), "w").write(line)
+if os.path.exists(os.path.join(src, tag + "_trace.log")):
+    for line in open(os.path.join(src, tag + "_trace.log"), errors="replace"):
+        if line.startswith('{"metric"'):
+            open(os.path.join(dst, tag + "_bench_under_trace.json"), "w").write(line)
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in ("_fetch", "_write", "_sq", "_sq2"):
     f = find(tag + d, "counter_collection.csv")
@@ -43,5 +44,10 @@ for k, cs in pmc.items():
         out[k]["hbm_read_bytes_corrected"] = out[k]["FETCH_SIZE"] * 1024 * 2
         out[k]["hbm_write_bytes"] = out[k]["WRITE_SIZE"] * 1024
         out[k]["hbm_traffic_bytes"] = out[k]["hbm_read_bytes_corrected"] + out[k]["hbm_write_bytes"]
+# tie the summary to the build and workload it was taken on (bench.py quotes it only when both match)
+sys.path.insert(0, ROOT)
+import bench
+out["build_id"] = bench.build_id()
+out["workload"] = {"frames": 8192, "frame_bytes": 131072, "level": 1, "command": "bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end"}
 json.dump(out, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))
