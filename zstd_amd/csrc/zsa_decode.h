@@ -614,7 +614,6 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
         }
         wv_sync();
         if (S->err) return 0;
-        u32 fencedPos = outPos;
         while (nbSeq) {
             u32 const n = nbSeq < ZSA_WAVE ? nbSeq : ZSA_WAVE;
             // -- stage the bytes this batch can consume (<= 64 x 89 bits below ptr + 8) into LDS, 16 per lane
@@ -628,10 +627,12 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                 const u8* const c = stageLo + 16u * (u32)lane;
                 if (c + 16 <= stageHi) { u64 const a0 = zsa_ld64(c), a1 = zsa_ld64(c + 8); __builtin_memcpy(S->bits + 16u * (u32)lane, &a0, 8); __builtin_memcpy(S->bits + 16u * (u32)lane + 8, &a1, 8); }
                 else if (c < stageHi) { for (u32 k = 0; c + k < stageHi; k++) S->bits[16u * (u32)lane + k] = c[k]; }
-                wv_sync();
+                wv_lds_fence();   // (LDS only: one wave, LDS operations complete in order)
             }
 #define ZSA_RELOAD(b) zsa_br_reload_staged(b, S->bits, stageLo, stageHi)
-            // -- zstd_decompress_block.c:1185-1299 ZSTD_decodeSequence, n times on lane 0
+            // -- zstd_decompress_block.c:1185-1299 ZSTD_decodeSequence, n times on lane 0.  (Measured, round 2: the same loop run by
+            // the whole wave on scalar registers -- one LDS round trip and ~70 scalar instructions per sequence -- is no faster:
+            // 12 resident waves share the CU's one scalar unit, whereas lane-0 vector code spreads over four SIMDs.)
             if (lane == 0) {
                 for (u32 i = 0; i < n; i++) {
                     ZsaSeqCell const ll = S->ll[stLL], ml = S->ml[stML], of = S->of[stOF];
@@ -670,6 +671,9 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
             }
 #undef ZSA_RELOAD
             ZSA_PROF(S, lane, 4);
+            // The one point of a batch that waits for global memory: the output of earlier batches (which this batch's matches
+            // read) was stored before the ~64 sequences above were decoded, so the wait is short.  Every other hand-over
+            // between lanes below goes through LDS and needs only the in-order guarantee of a single wave.
             wv_sync();
             // -- execute the batch (zstd_decompress_block.c:873-1060 semantics)
             u32 const myLL = (u32)lane < n ? S->seqLL[lane] : 0;
@@ -691,7 +695,7 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                 u32 const c = wv_shfl(code, first);
                 if (lane == 0) zsa_raise(S, c);
             }
-            wv_sync();
+            wv_lds_fence();
             if (S->err) return 0;
             u32 const totalLit = wv_shfl(litIncl, 63), totalOut = wv_shfl(totIncl, 63);
             // literals of the whole batch
@@ -700,8 +704,7 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                 while (lo < hi) { u32 const mid = (lo + hi + 1) >> 1; if (S->litStart[mid] <= t) lo = mid; else hi = mid - 1; }
                 dst[outPos + S->outStart[lo] + (t - S->litStart[lo])] = litPtr[litPos + t];
             }
-            wv_sync();
-            if (fencedPos < outPos) fencedPos = outPos;   // everything before this batch is visible now
+            wv_lds_fence();
             ZSA_PROF(S, lane, 5);
             // matches.  Phase I: every match whose source lies entirely before this batch's output (already visible) is
             // independent of the batch -- all of them are copied at once, flattened over the lanes.
@@ -712,7 +715,7 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
             S->mStart[lane] = mIncl - (indep ? myML : 0);
             u64 const depMask = wv_ballot((u32)lane < n && !indep && myML > 0);
             u32 const totalInd = wv_shfl(mIncl, 63);
-            wv_sync();
+            wv_lds_fence();
             for (u32 t = (u32)lane; t < totalInd; t += ZSA_WAVE) {
                 u32 lo = 0, hi = n - 1;
                 while (lo < hi) { u32 const mid = (lo + hi + 1) >> 1; if (S->mStart[mid] <= t) lo = mid; else hi = mid - 1; }
@@ -724,15 +727,17 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                 s64 const p = (s64)o - (s64)off + (off >= ml ? k : k % off);
                 dst[o + k] = p < 0 ? C.dictContent[(s64)C.dictSize + p] : dst[p];
             }
-            if (depMask) wv_sync();   // phase II may read what phase I wrote
-            if (fencedPos < outPos) fencedPos = outPos;
-            // Phase II: the others, in order
+            if (depMask) wv_sync();   // phase II may read the literals and the phase-I matches of this batch
+            // Phase II: the others, in order.  Only a match whose source reaches the output of an earlier phase-II match that
+            // has not been waited for yet needs another wait (`pending` = lowest such output position).
+            u32 pending = 0xFFFFFFFFu;
             for (u64 m = depMask; m; m &= m - 1) {
                 u32 const i = (u32)__builtin_ctzll(m);
                 u32 const ml = S->seqML[i], off = S->seqOF[i];
                 u32 const o = outPos + S->outStart[i] + S->seqLL[i];
                 u32 const span = off < ml ? off : ml;            // distinct source bytes
-                if ((u64)o + span > (u64)off + fencedPos) { wv_sync(); fencedPos = o; }   // source reaches unfenced output
+                if ((u64)o + span > (u64)off + pending) { wv_sync(); pending = 0xFFFFFFFFu; }
+                if (o < pending) pending = o;
                 if (off >= ml) {
                     for (u32 t = (u32)lane; t < ml; t += ZSA_WAVE) {
                         s64 const p = (s64)o - (s64)off + t;
@@ -748,7 +753,7 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
             outPos += totalOut; litPos += totalLit;
             nbSeq -= n;
             ZSA_PROF(S, lane, 6);
-            wv_sync();   // the batch arrays are rewritten by lane 0 next
+            wv_lds_fence();   // the batch arrays are rewritten by lane 0 next
             if (endBad) { if (lane == 0) zsa_raise(S, ZSA_corruption_detected); wv_sync(); return 0; }
         }
         if (lane == 0) { S->u[ZU_tmp] = r0; S->u[ZU_hufOff] = r1; S->u[ZU_hufCSize] = r2; }
