@@ -71,12 +71,11 @@ extern "C" size_t emu_decompress(void* dst, size_t cap, const void* src, size_t 
 }
 
 #ifdef ZSA_EMU_ENCODE
-struct EncArgs { ZsaEncShared* S; u32* ht; ZsaEncParams P; const u8* src; u64 srcSize; u8* dst; u64 cap; ZsaEncScratch W; const ZsaCDictDev* cd; int dictMode; u64 result; ZsaTabLds lds; };
+struct EncArgs { ZsaEncShared* S; u32* ht; ZsaEncParams P; const u8* src; u64 srcSize; u8* dst; u64 cap; ZsaEncScratch W; const ZsaCDictDev* cd; int dictMode; u64 result; };
 static void enc_entry(void* a)
 {
     EncArgs* A = (EncArgs*)a;
-    u64 r = A->lds.lo ? zsa_encode_frame<2>(A->S, A->ht, A->P, A->src, A->srcSize, A->dst, A->cap, A->W, A->cd, A->dictMode, A->lds)
-          : A->P.strat >= 3 ? zsa_encode_frame<1>(A->S, A->ht, A->P, A->src, A->srcSize, A->dst, A->cap, A->W, A->cd, A->dictMode)
+    u64 r = A->P.strat >= 3 ? zsa_encode_frame<1>(A->S, A->ht, A->P, A->src, A->srcSize, A->dst, A->cap, A->W, A->cd, A->dictMode)
                             : zsa_encode_frame<0>(A->S, A->ht, A->P, A->src, A->srcSize, A->dst, A->cap, A->W, A->cd, A->dictMode);
     if (wv_lane() == 0) A->result = r;
 }
@@ -107,25 +106,6 @@ extern "C" size_t emu_compress_level(void* dst, size_t cap, const void* src, siz
     if (zsa_resolveCParams(&cp, level, n, 0, zsa_cpm_noAttachDict)
         || ((size_t)4 << cp.hlog) + zsa_auxTableBytes(cp.strat, cp.wlog, cp.hlog, cp.clog) > ((size_t)5 << 20)) return (size_t)ZSA_ERR(ZSA_parameter_unsupported);
     EncArgs A = { &S, ht, { cp.wlog, cp.hlog, cp.mml, cp.tlen, cp.clog, cp.strat, cp.slog }, n ? (const u8*)src : empty + 8, n, (u8*)dst, cap, { seq, lit, tmp, park }, nullptr, 0, 0 };
-    emu_run_wave(enc_entry, &A);
-    return (size_t)A.result;
-}
-
-// the kernel body with the match table in (emulated) LDS: 24-bit cells, hoisted-window parse
-extern "C" size_t emu_compress_lds(void* dst, size_t cap, const void* src, size_t n, int level)
-{
-    static ZsaEncShared S;
-    static u16* lo = (u16*)malloc(2 << 15);
-    static u8* hi = (u8*)malloc(1 << 15);
-    static u64* seq = (u64*)malloc(8 * (32768 + 64));
-    static u8* lit = (u8*)malloc(ZSA_BLOCKSIZE_MAX + 128);
-    static u8* tmp = (u8*)malloc(ZSA_BLOCKSIZE_MAX * 2 + 512);
-    static ZsaFseCT park[3];
-    static const u8 empty[16] = {0};
-    ZsaCParams cp;
-    if (zsa_resolveCParams(&cp, level, n, 0, zsa_cpm_noAttachDict) || !zsa_ldsTableFits(cp.strat, cp.tlen, cp.hlog, n, (size_t)3 << 15))
-        return (size_t)ZSA_ERR(ZSA_parameter_unsupported);
-    EncArgs A = { &S, nullptr, { cp.wlog, cp.hlog, cp.mml, cp.tlen, cp.clog, cp.strat, cp.slog }, n ? (const u8*)src : empty + 8, n, (u8*)dst, cap, { seq, lit, tmp, park }, nullptr, 0, 0, { lo, hi } };
     emu_run_wave(enc_entry, &A);
     return (size_t)A.result;
 }

@@ -95,6 +95,8 @@ ZSA_DEV unsigned long long wv_clock() { return 0; }
 ZSA_DEV unsigned wv_atomic_add_lds(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 ZSA_DEV unsigned wv_atomic_or_lds(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
 ZSA_DEV unsigned wv_atomic_max_lds(unsigned* p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
+ZSA_DEV unsigned wv_atomic_xor_lds(unsigned* p, unsigned v) { unsigned o = *p; *p = o ^ v; return o; }
+ZSA_DEV unsigned wv_atomic_and_lds(unsigned* p, unsigned v) { unsigned o = *p; *p = o & v; return o; }
 ZSA_DEV unsigned wv_atomic_add_global(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 ZSA_DEV void wv_atomic_max_global(unsigned* p, unsigned v) { if (v > *p) *p = v; }
 ZSA_DEV void wv_device_fence() {}

@@ -51,37 +51,45 @@ struct ZsaHufNode { u32 count; u16 parent; u8 byte; u8 nbBits; };
 struct ZsaSeqEncScratch { u8 code[3][64]; u16 stBits[3][64]; u8 stNb[3][64]; u32 bitbuf[256]; };
 
 // LDS of one compressing workgroup.  Sized for 16 workgroups per CU (160 KiB / 16): the stages of a block reuse the
-// same bytes.  Only the Huffman tables (literal "repeat" mode) and the block-to-block scalars outlive a block.  Below
+// same bytes.  The parse stage takes everything (source ring, the match table's filter, the cell bitmap); the previous
+// block's Huffman table -- the one thing of the entropy stages that outlives a block in LDS -- waits in the workgroup's
+// global scratch meanwhile.  Below
 // ZSTD_lazy the FSE sequence tables of a block are never used again (set_repeat is only reachable with dictionary
 // tables, which are re-read from the digest: zstd_compress_sequences.c:180-205); from ZSTD_lazy on a later block may
 // price and repeat them (:206-232), so they are parked in the workgroup's global scratch (ZsaEncScratch::park).
+#define ZSA_FILT_HLOG_MAX 13u     // the chunk path's LDS filter covers match tables of up to 1 << 13 cells
 struct ZsaEncShared {
-    ZsaHufCT hufPrev, hufNext;
-    u32 count[256];                        // histogram of the stage at hand
     union {
-        struct {   // Huffman table construction (huf_compress.c:596-766)
-            ZsaHufNode node[2 * 256 + 2];
-            u16 rpBase[192], rpCurr[192];
-        };
-        struct {   // table descriptions, bit packing, sequence tables
+        struct {   // entropy stages
+            ZsaHufCT hufPrev, hufNext;
+            u32 count[256];                        // histogram of the stage at hand
             union {
-                struct {
-                    u8  huffWeight[256];
-                    s16 norm[256];
-                    u16 cumul[258];
-                    u8  tableSymbol[512];
-                    // small FSE table for Huffman weights (tableLog <= 6, symbols <= 12)
-                    u16 wtNext[64]; s32 wtDfs[16]; u32 wtDnb[16];
+                struct {   // Huffman table construction (huf_compress.c:596-766)
+                    ZsaHufNode node[2 * 256 + 2];
+                    u16 rpBase[192], rpCurr[192];
                 };
-                ZsaSeqEncScratch enc;      // stream packing (Huffman streams, sequence bitstream)
+                struct {   // table descriptions, bit packing, sequence tables
+                    union {
+                        struct {
+                            u8  huffWeight[256];
+                            s16 norm[256];
+                            u16 cumul[258];
+                            u8  tableSymbol[512];
+                            // small FSE table for Huffman weights (tableLog <= 6, symbols <= 12)
+                            u16 wtNext[64]; s32 wtDfs[16]; u32 wtDnb[16];
+                        };
+                        ZsaSeqEncScratch enc;      // stream packing (Huffman streams, sequence bitstream)
+                    };
+                    ZsaFseCT ll, of, ml;
+                };
+                struct { u32 bLit[64], bSrc[64]; };   // literal gather
             };
-            ZsaFseCT ll, of, ml;
         };
-        struct { u32 bLit[64], bSrc[64]; };   // literal gather
-        struct {   // parse stage (zsa_parse.h): source ring + sequence staging + shared-cell tags
+        struct {   // parse stage (zsa_parse.h): source ring + sequence staging + filter + cell bitmap / shared-cell tags
             u32 ring[ZSA_RING_BYTES / 4 + 4];
             u64 seqStage[64];
-            u8  tags[ZSA_NTAGS];
+            u32 filt[(1u << ZSA_FILT_HLOG_MAX) / 8];
+            union { u32 dupBits[(1u << ZSA_FILT_HLOG_MAX) / 32]; u8 tags[ZSA_NTAGS]; };
         };
     };
     // entropy state carried between blocks (zstd_compress_internal.h ZSTD_compressedBlockState_t)
@@ -92,6 +100,7 @@ struct ZsaEncShared {
     u32 u[24];
     u64 prof[ZSA_NPROF], profLast;
 };
+static_assert(sizeof(ZsaEncShared) + 8 <= 160 * 1024 / 16, "16 compressing workgroups per CU");
 enum { EU_nbSeq, EU_litSize, EU_lastLL, EU_cSize, EU_litCSize, EU_hType, EU_single, EU_hSize, EU_useOld,
        EU_s0, EU_s1, EU_s2, EU_s3, EU_op, EU_tmp, EU_longType, EU_longPos, EU_raw };
 
@@ -1566,19 +1575,11 @@ ZSA_DEV void zsa_gatherLiterals(ZsaEncShared* S, const u64* seq, u32 nbSeq, cons
 // Returns bytes written or (u64)-error (uniform).
 struct ZsaEncScratch { u64* seq; u8* lit; u8* tmp; ZsaFseCT* park; };   // park: 3 sequence tables (LL, OF, ML) of the last compressed block
 
-// FAMILY 0: ZSTD_fast / ZSTD_dfast (and the dictionary variants); FAMILY 1: ZSTD_greedy / ZSTD_lazy / ZSTD_lazy2; FAMILY 2:
-// ZSTD_fast without a dictionary and with step 2 (levels 1 and 2), match table in LDS (`ldsTab`, 3 << hashLog bytes; the
-// global `hashTable` is not touched).  Each is compiled into a kernel of its own: each parser then gets the whole register
-// budget (one kernel holding two of them spilled).
-ZSA_HD bool zsa_ldsTableFits(u32 strat, u32 tlen, u32 hlog, u64 srcSize, size_t ldsTableBytes)
-{   // a 24-bit cell holds the position (indices run up to srcSize + 2) and at least 5 fingerprint bits
-    if (strat != 1 || tlen > 1 || srcSize == 0 || srcSize > (1u << 19) - 4) return false;
-    return ((size_t)3 << hlog) <= ldsTableBytes;
-}
+// FAMILY 0: ZSTD_fast / ZSTD_dfast (and the dictionary variants); FAMILY 1: ZSTD_greedy / ZSTD_lazy / ZSTD_lazy2.  Each is
+// compiled into a kernel of its own: each parser then gets the whole register budget (one kernel holding both spilled).
 template <int FAMILY>
 ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams& P, const u8* src, u64 srcSize64,
-                             u8* dst, u64 dstCapacity, const ZsaEncScratch& W, const ZsaCDictDev* cd, int dictMode,
-                             ZsaTabLds ldsTab = ZsaTabLds())
+                             u8* dst, u64 dstCapacity, const ZsaEncScratch& W, const ZsaCDictDev* cd, int dictMode)
 {
     int const lane = wv_lane();
     if (srcSize64 > 0xE0000000ull) return ZSA_ERR(ZSA_srcSize_wrong);
@@ -1617,11 +1618,7 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
     // per-frame state (zstd_compress.c:2045-2225, 1863-1872; with a dictionary :2270-2329, :2347-2426, :5027-5044)
     ZsaWindow Wn;
     Wn.base = src - 2; Wn.dictBase = src - 2; Wn.dictLimit = 2; Wn.lowLimit = 2; Wn.loadedDictEnd = 0; Wn.dms = nullptr;
-    if (FAMILY == 2) {
-        u32* const lo = (u32*)ldsTab.lo; u32* const hi = (u32*)ldsTab.hi;
-        for (u32 i = (u32)lane; i < (1u << P.hlog) / 2u; i += ZSA_WAVE) lo[i] = 0;
-        for (u32 i = (u32)lane; i < (1u << P.hlog) / 4u; i += ZSA_WAVE) hi[i] = 0;
-    } else if (cd && dictMode == zsa_dm_copy) {   // ZSTD_copyCDictTableIntoCCtx: tags removed
+    if (cd && dictMode == zsa_dm_copy) {   // ZSTD_copyCDictTableIntoCCtx: tags removed
         for (u32 i = (u32)lane; i < (1u << P.hlog); i += ZSA_WAVE) hashTable[i] = cd->hashTable[i] >> 8;
     } else {
         // ZSTD_dfast: the short-hash ("chain") table follows the long one in the same scratch region; greedy/lazy/lazy2: the
@@ -1685,7 +1682,9 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
     // Without a dictionary the match table is touched by the wave parser only, which then keeps a fingerprint of the 4
     // bytes at each position in the cell bits the position does not need (zsa_parse.h); indices run up to srcSize + 2.
     u32 fpPosBits = 0;
-    if (!cd && P.strat == 1) { u32 const bits = 32u - (u32)__builtin_clz(srcSize + 2u); if (bits <= (FAMILY == 2 ? 19u : 26u)) fpPosBits = bits; }
+    if (!cd && P.strat == 1) { u32 const bits = 32u - (u32)__builtin_clz(srcSize + 2u); if (bits <= 26u) fpPosBits = bits; }
+    // chunk path (zsa_parse.h): levels 1-2 (step 2) with a table the LDS filter covers
+    bool const chunkParse = FAMILY == 0 && fpPosBits != 0 && P.tlen <= 1 && P.hlog <= ZSA_FILT_HLOG_MAX;
     int const literalsDisabled = (P.strat == 1) && (P.tlen > 0);   // zstd_compress_internal.h:605-618
     u32 const maxDist = 1u << P.wlog;
     ZsaLazyCtx LZ;   // greedy / lazy / lazy2 (zsa_lazy.h): match-finder state that lives across the blocks of the frame
@@ -1744,8 +1743,6 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
                 u32 lastLL = 0, nbSeq;
                 if (FAMILY == 1) {   // greedy / lazy / lazy2 (never with a dictionary here): wave-uniform, zsa_lazy.h
                     nbSeq = zsa_parse_lazy(LZ, Wn.dictLimit, ip, blockSize, P.strat - 3, rep, W.seq, &lastLL, lane);
-                } else if (FAMILY == 2) {   // ZSTD_fast, table in LDS: hoisted-window parse (zsa_parse.h)
-                    nbSeq = zsa_parse_fast_wave_tab<ZsaTabLds>(S, ldsTab, S->ring, S->seqStage, S->tags, P, Wn.base, Wn.dictLimit, ip, blockSize, rep, W.seq, &lastLL, fpPosBits, lane);
                 } else if (P.strat == 2) {   // ZSTD_dfast (never with a dictionary here): serial for now, zsa_dfast.h
                     nbSeq = 0;
                     if (lane == 0) nbSeq = zsa_parse_dfast(hashTable, hashTable + (1u << P.hlog), P, Wn.base, Wn.dictLimit, ip, blockSize, rep, W.seq, &lastLL);
@@ -1756,8 +1753,29 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
                     if (lane == 0) nbSeq = zsa_parse_fast(hashTable, P, Wn.base, Wn.dictLimit, Wn.loadedDictEnd, ip, blockSize, rep, W.seq, &lastLL);
                     nbSeq = wv_shfl(nbSeq, 0); lastLL = wv_shfl(lastLL, 0);
                     rep[0] = wv_shfl(rep[0], 0); rep[1] = wv_shfl(rep[1], 0);
-                } else {
-                    nbSeq = zsa_parse_fast_wave(S, hashTable, S->ring, S->seqStage, S->tags, P, Wn.base, Wn.dictLimit, ip, blockSize, rep, W.seq, &lastLL, fpPosBits, lane);
+                } else {   // ZSTD_fast without a dictionary segment: the wave parser (zsa_parse.h)
+                    // its stage takes the whole LDS: the previous block's Huffman table waits in global scratch meanwhile
+                    u32* const park = (u32*)W.tmp;
+                    for (u32 i = (u32)lane; i < sizeof(ZsaHufCT) / 4; i += ZSA_WAVE) park[i] = ((const u32*)&S->hufPrev)[i];
+                    wv_sync();
+                    if (chunkParse) {   // level 1 / 2: chunk path with the table's filter in LDS
+                        u32 const cells = 1u << P.hlog;
+                        if (isFirstBlock) { for (u32 i = (u32)lane; i < cells / 8u; i += ZSA_WAVE) S->filt[i] = 0; }
+                        else {   // the filter mirrors the top 4 bits of every cell
+                            for (u32 i = (u32)lane; i < cells / 8u; i += ZSA_WAVE) {
+                                u32 w = 0;
+                                for (u32 k = 0; k < 8; k++) w |= (hashTable[8u * i + k] >> 28) << (4u * k);
+                                S->filt[i] = w;
+                            }
+                        }
+                        for (u32 i = (u32)lane; i < sizeof(S->dupBits) / 4; i += ZSA_WAVE) S->dupBits[i] = 0;
+                        wv_sync();
+                        nbSeq = zsa_parse_fast_wave_filt(S, hashTable, S->filt, S->dupBits, S->ring, S->seqStage, P, Wn.base, Wn.dictLimit, ip, blockSize, rep, W.seq, &lastLL, fpPosBits, lane);
+                    } else {
+                        nbSeq = zsa_parse_fast_wave(S, hashTable, S->ring, S->seqStage, S->tags, P, Wn.base, Wn.dictLimit, ip, blockSize, rep, W.seq, &lastLL, fpPosBits, lane);
+                    }
+                    wv_sync();
+                    for (u32 i = (u32)lane; i < sizeof(ZsaHufCT) / 4; i += ZSA_WAVE) ((u32*)&S->hufPrev)[i] = park[i];
                 }
                 wv_sync();
                 if (lane == 0) {

@@ -77,12 +77,10 @@ zsa_k_decompress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ resu
 // ZSTD_dfast and ZSTD_greedy rows there, chosen per frame by its size): each kernel then walks all frames with a counter of
 // its own and takes the ones of its family; `reportUnsupported` says which of the two writes the error word of a frame
 // neither can take (0: not this one, 1: this one, 2: this one, and it is the only launch).
-// FAMILY 2 (zsa_k_compress_lds) keeps the match table of ZSTD_fast frames in LDS (`ldsTab`, ldsTableBytes of dynamic shared
-// memory); a launch that runs it passes the same ldsTableBytes to the FAMILY 0 kernel, which then leaves those frames alone.
 template <int FAMILY>
 ZSA_DEV void zsa_compress_body(ZsaEncShared& S, u32& nextFrame, const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
                                u32* __restrict__ counter, u8* __restrict__ scratch, const ZsaEncLayout L, int level, const ZsaCDictDev* cd,
-                               int reportUnsupported, u64* __restrict__ prof, u32 ldsTableBytes = 0, ZsaTabLds ldsTab = ZsaTabLds())
+                               int reportUnsupported, u64* __restrict__ prof)
 {
     if (threadIdx.x == 0) { for (int i = 0; i < ZSA_NPROF; i++) S.prof[i] = 0; S.profLast = wv_clock(); }
     u8* const wg = scratch + (size_t)blockIdx.x * L.stride;
@@ -107,17 +105,7 @@ ZSA_DEV void zsa_compress_body(ZsaEncShared& S, u32& nextFrame, const ZsaFrameDe
         // (a frame larger than the launch was sized for -- sizes linked on the device -- is refused rather than overrun)
         bool const unsupported = bad || !(cp.strat == 1 || (cp.strat >= 2 && cp.strat <= 5 && !cd)) || tableBytes > L.htBytes
                               || (d.srcSize > L.blockCap && L.blockCap < ZSA_BLOCKSIZE_MAX);
-        bool const toLds = !unsupported && !cd && ldsTableBytes && zsa_ldsTableFits(cp.strat, cp.tlen, cp.hlog, d.srcSize, ldsTableBytes);
-        if (FAMILY == 2) {
-            if (toLds) {
-                ZsaEncParams P; P.wlog = cp.wlog; P.hlog = cp.hlog; P.mml = cp.mml; P.tlen = cp.tlen; P.clog = cp.clog; P.strat = cp.strat; P.slog = cp.slog;
-                ZsaTabLds T = ldsTab; T.hi = (u8*)(T.lo + ((size_t)1 << cp.hlog));
-                u64 const r = zsa_encode_frame<2>(&S, zsa_hashTable, P, d.src, d.srcSize, d.dst, d.dstCapacity, W, nullptr, zsa_dm_none, T);
-                if (threadIdx.x == 0) results[f] = r;
-            }
-        } else if (toLds) {
-            // taken by the LDS-table kernel of this launch
-        } else if (unsupported) {
+        if (unsupported) {
             if (reportUnsupported && threadIdx.x == 0) results[f] = ZSA_ERR(ZSA_parameter_unsupported);
         } else if ((cp.strat >= 3) == (FAMILY == 1)) {
             ZsaEncParams P; P.wlog = cp.wlog; P.hlog = cp.hlog; P.mml = cp.mml; P.tlen = cp.tlen; P.clog = cp.clog; P.strat = cp.strat; P.slog = cp.slog;
@@ -134,26 +122,11 @@ ZSA_DEV void zsa_compress_body(ZsaEncShared& S, u32& nextFrame, const ZsaFrameDe
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZSA_ENC_WAVES, ZSA_ENC_WAVES)))
 zsa_k_compress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
                u32* __restrict__ counter, u8* __restrict__ scratch, const ZsaEncLayout L, int level, const ZsaCDictDev* cd, int reportUnsupported,
-               u64* __restrict__ prof, u32 ldsTableBytes)
+               u64* __restrict__ prof)
 {
     __shared__ ZsaEncShared S;
     __shared__ u32 nextFrame;
-    zsa_compress_body<0>(S, nextFrame, frames, results, nFrames, counter, scratch, L, level, cd, reportUnsupported, prof, ldsTableBytes);
-}
-// ZSTD_fast frames (levels 1-2, no dictionary) whose match table fits LDS: ldsTableBytes of dynamic shared memory hold it
-// (24-bit cells, 3 << hashLog bytes), so a CU runs 160 KiB / (table + stage LDS) workgroups and the register budget is wide.
-#ifndef ZSA_LDS_WAVES
-#define ZSA_LDS_WAVES 2
-#endif
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, ZSA_LDS_WAVES)))
-zsa_k_compress_lds(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
-                   u32* __restrict__ counter, u8* __restrict__ scratch, const ZsaEncLayout L, int level, u64* __restrict__ prof, u32 ldsTableBytes)
-{
-    __shared__ ZsaEncShared S;
-    __shared__ u32 nextFrame;
-    extern __shared__ __align__(16) u8 zsa_dynLds[];
-    ZsaTabLds T; T.lo = (u16*)zsa_dynLds; T.hi = nullptr;
-    zsa_compress_body<2>(S, nextFrame, frames, results, nFrames, counter, scratch, L, level, nullptr, 0, prof, ldsTableBytes, T);
+    zsa_compress_body<0>(S, nextFrame, frames, results, nFrames, counter, scratch, L, level, cd, reportUnsupported, prof);
 }
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZSA_ENC_WAVES, ZSA_ENC_WAVES)))
 zsa_k_compress_lazy(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
@@ -198,7 +171,7 @@ struct zsa_batch_s {
     u64  maxSrcSize;
     bool sizesOnDevice;          // srcSize words were rewritten on the device (zsa_batch_link_src_sizes): the host copy is stale
     // what a compress launch at (planLevel, planDict) needs (zsa_plan_compress)
-    int  planLevel; const void* planDict; bool planValid; u32 planLdsBytes; bool planNeedGlobal; u64 planHtBytes;
+    int  planLevel; const void* planDict; bool planValid; u64 planHtBytes;
     unsigned lastWG, lastLDS;
     u64* d_prof; int profOn;
 };
@@ -399,32 +372,18 @@ static size_t zsa_check_device(const zsa_batch* b, int dictDevice)
     return 0;
 }
 
-// What a compress launch of this batch needs: the match-table bytes of its most demanding frame (sizes the workspace),
-// and -- opt-in, see below -- whether the LDS-table kernel takes part.
-#ifndef ZSA_LDS_TABLE_MAX
-#define ZSA_LDS_TABLE_MAX ((size_t)3 << 14)
-#endif
+// What a compress launch of this batch needs: the match-table bytes of its most demanding frame (sizes the workspace).
 static void zsa_plan_compress(zsa_batch* b, int level, const zsa_CDict* cdict)
 {
     if (b->planValid && b->planLevel == level && b->planDict == (const void*)cdict) return;
-    b->planLevel = level; b->planDict = cdict; b->planValid = true; b->planLdsBytes = 0; b->planNeedGlobal = false; b->planHtBytes = 4096;
-    // Measured (profiles/r02_lds_table_*): with the table in LDS a CU holds 4 workgroups instead of 16 and, although each frame
-    // then parses 1.7 x faster and the table traffic is gone, a launch takes 2.3 x longer -- the path is bound by instructions
-    // issued per frame over many resident waves, not by table locality.  The kernel stays as an opt-in experiment.
-    bool const ldsOptIn = getenv("ZSA_LDS_TABLE") != NULL && !cdict;
-    if (b->sizesOnDevice) {   // sizes unknown here: the largest tables the workgroup arena may hold
-        b->planNeedGlobal = true; b->planHtBytes = ZSA_HT_BYTES;
-        if (ldsOptIn && level <= 2) b->planLdsBytes = 3u << 13;
-        return;
-    }
+    b->planLevel = level; b->planDict = cdict; b->planValid = true; b->planHtBytes = 4096;
+    if (b->sizesOnDevice) { b->planHtBytes = ZSA_HT_BYTES; return; }   // sizes unknown here: the largest tables the workgroup arena may hold
     for (size_t i = 0; i < b->nFrames; i++) {
         ZsaCParams cp; int dictMode = zsa_dm_none;
         u64 const n = b->h_frames[i].srcSize;
         int const bad = cdict ? zsa_resolveCDictUse(&cp, &dictMode, cdict->cp, cdict->level, cdict->dictSize, n)
                               : zsa_resolveCParams(&cp, level, n, 0, zsa_cpm_noAttachDict);
-        if (bad) { b->planNeedGlobal = true; continue; }
-        if (ldsOptIn && zsa_ldsTableFits(cp.strat, cp.tlen, cp.hlog, n, ZSA_LDS_TABLE_MAX)) { u32 const t = 3u << cp.hlog; if (t > b->planLdsBytes) b->planLdsBytes = t; continue; }
-        b->planNeedGlobal = true;
+        if (bad) continue;
         u64 const t = ((u64)4 << cp.hlog) + zsa_auxTableBytes(cp.strat, cp.wlog, cp.hlog, cp.clog);
         if (t <= ZSA_HT_BYTES && t > b->planHtBytes) b->planHtBytes = t;   // (larger ones are refused per frame by the kernel)
     }
@@ -457,23 +416,14 @@ extern "C" size_t zsa_compress_enqueue(zsa_batch* b, int level, const zsa_CDict*
     bool const fam0 = cdict || level <= 4, fam1 = !cdict && level >= 4;
     const ZsaCDictDev* const cd = cdict ? (const ZsaCDictDev*)cdict->d_cd : (const ZsaCDictDev*)nullptr;
     u64* const prof = b->profOn ? b->d_prof : (u64*)nullptr;
-    u32 const ldsBytes = fam0 ? b->planLdsBytes : 0;
-    bool const fam0run = fam0 && (b->planNeedGlobal || fam1 || !ldsBytes);
-    if (ldsBytes) {
-        size_t const ldsWG = ldsPerWG + ldsBytes;
-        unsigned const gridL = zsa_grid(b, ldsWG);
-        hipLaunchKernelGGL(zsa_k_compress_lds, dim3(gridL), dim3(64), ldsBytes, (hipStream_t)stream,
-                           b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter + 32, b->d_encScratch, L, level, prof, ldsBytes);
-        b->lastWG = gridL; b->lastLDS = (unsigned)ldsWG;
-    }
-    if (fam0run)
+    if (fam0)
         hipLaunchKernelGGL(zsa_k_compress, dim3(grid), dim3(64), 0, (hipStream_t)stream,
-                           b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter, b->d_encScratch, L, level, cd, fam1 ? 1 : 2, prof, ldsBytes);
+                           b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter, b->d_encScratch, L, level, cd, fam1 ? 1 : 2, prof);
     if (fam1)   // same scratch: the two launches run one after the other on the stream
         hipLaunchKernelGGL(zsa_k_compress_lazy, dim3(grid), dim3(64), 0, (hipStream_t)stream,
                            b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter + 16, b->d_encScratch, L, level, cd, fam0 ? 0 : 2, prof);
     HIPCHK(hipGetLastError());
-    if (!ldsBytes) { b->lastWG = grid; b->lastLDS = (unsigned)ldsPerWG; }
+    b->lastWG = grid; b->lastLDS = (unsigned)ldsPerWG;
     return 0;
 }
 extern "C" size_t zsa_decompress_enqueue(zsa_batch* b, const zsa_DDict* ddict, void* stream)

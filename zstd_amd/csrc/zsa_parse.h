@@ -21,6 +21,13 @@
 // Source bytes come from an LDS ring that trails the parse position (filled 1 KiB per step with 16-byte coalesced loads),
 // so the per-sequence dependency chain is LDS latency except for match candidates older than the ring, which come
 // from L2.  Sequences are staged in LDS and written out 64 at a time.
+//
+// Level 1 / 2 frames without a dictionary take the CHUNK path (ZsaTabFilt, the block at the top of the window loop): the
+// per-position work that does not depend on the parse state -- source word, hash, fingerprint, probe -- is done once for
+// 64 consecutive positions, and the probe does not touch the global table at all: an LDS array holds the top 4 fingerprint
+// bits of every cell, so only the position that wins a search reads its cell (one 4-byte load per match instead of a
+// 64-cell gather per window).  The general window evaluation remains as the path for everything the chunk path leaves
+// out (step > 2 after 128 bytes without a match, the last pairs of a block, table cells shared by neighbouring lanes).
 // Included by zsa_encode.h (uses zsa_hash / zsa_packseq / ZsaEncParams from there).
 #pragma once
 
@@ -163,26 +170,64 @@ template <int MLS> ZSA_DEV u32 zsa_hashT(u64 v, u32 hlog)
     return (u32)((v * 0xCF1BBCDCB7A56463ULL) >> (64 - hlog));
 }
 
-// Match-table accessors.  A logical cell is `cellBits` wide: the low posBits bits hold the position, the bits above them a
-// fingerprint of the 4 bytes at that position (or nothing, posBits == 0: plain 32-bit positions as in the reference).
+// Match-table accessors.  A cell is 32 bits: the low posBits bits hold the position, the bits above them a fingerprint of
+// the 4 bytes at that position (or nothing, posBits == 0: plain 32-bit positions as in the reference).
 struct ZsaTabGlobal {   // one 32-bit word per cell in the workgroup's global scratch
     u32* p;
-    static constexpr u32 cellBits = 32;
-    static constexpr bool lean = false;
+    static constexpr bool filtered = false;
     ZSA_MEM u32 ld(u32 h) const { return p[h]; }
     ZSA_MEM void st(u32 h, u32 c) const { p[h] = c; }
-    ZSA_MEM u32 ld16(u32) const { return 0; }
-    ZSA_MEM void st16(u32, u32) const {}
+    ZSA_MEM u32 fget(u32) const { return 0; }
+    ZSA_MEM void fxor(u32, u32) const {}
+    ZSA_MEM u32* dupWord(u32) const { return nullptr; }
 };
-struct ZsaTabLds {      // 24-bit cells in LDS, split into a 16-bit and an 8-bit array: 3 << hashLog bytes per frame
-    u16* lo; u8* hi;
-    static constexpr u32 cellBits = 24;
-    static constexpr bool lean = true;
-    ZSA_MEM u32 ld(u32 h) const { return (u32)lo[h] | ((u32)hi[h] << 16); }
-    ZSA_MEM void st(u32 h, u32 c) const { lo[h] = (u16)c; hi[h] = (u8)(c >> 16); }
-    ZSA_MEM u32 ld16(u32 h) const { return lo[h]; }
-    ZSA_MEM void st16(u32 h, u32 c) const { lo[h] = (u16)c; }
+// The same cells plus, in LDS, a FILTER: the top 4 bits of every cell (fingerprint bits), 8 cells per word, kept equal to
+// the global cell by every store.  `dup` is a bitmap of 1 << hashLog bits, all zero between uses (chunk set-up).
+struct ZsaTabFilt {
+    u32* p; u32* filt; u32* dup;
+    static constexpr bool filtered = true;
+    ZSA_MEM u32 ld(u32 h) const { return p[h]; }
+    ZSA_MEM u32 fget(u32 h) const { return (filt[h >> 3] >> ((h & 7u) * 4u)) & 15u; }
+    // d = old nibble ^ new nibble.  An atomic xor: lanes that update different cells of one word do not disturb each other
+    ZSA_MEM void fxor(u32 h, u32 d) const { (void)wv_atomic_xor_lds(&filt[h >> 3], d << ((h & 7u) * 4u)); }
+    ZSA_MEM void st(u32 h, u32 c) const { p[h] = c; u32 const d = fget(h) ^ (c >> 28); if (d) fxor(h, d); }
+    ZSA_MEM u32* dupWord(u32 h) const { return &dup[h >> 5]; }
 };
+
+// One round of match extension for the chunk path: lanes 0..15 compare 8 bytes each forwards from (ip, m) (capped at
+// iend), lanes 48..63 one byte each backwards from (ipB-1, mB-1) for at most maxBack bytes; 128 + 16 bytes per side keep a
+// candidate that is older than the ring to one or two cache lines.  Longer runs continue in the wide loops.
+ZSA_DEV void zsa_extend16(const ZsaRing& R, u32 ip, u32 m, u32 iend, u32 ipB, u32 mB, u32 maxBack, u32* fwd, u32* bwd, int lane)
+{
+    if (!(ip + 136 <= iend && ip + 136 <= R.hi && ipB >= R.lo + 16)) { zsa_extend_wave(R, ip, m, iend, ipB, mB, maxBack, fwd, bwd, lane); return; }
+    bool const fw = lane < 16;
+    u32 const k = (u32)lane - 48u;
+    u32 const a = fw ? ip + 8u * (u32)lane : ipB - 1 - k, b = fw ? m + 8u * (u32)lane : mB - 1 - k;
+    u64 const sa = zsa_ring64(R, a);                                 // masked ring address: legal in every lane
+    u64 sb;
+    if (mB >= R.lo + 16) sb = zsa_ring64(R, b);                      // uniform: the candidate lies in the ring as well
+    else { sb = ~sa; if (fw || (lane >= 48 && k < maxBack)) sb = wv_ldg64_now(R.src + b); }
+    u64 const diff = sa ^ sb;
+    u32 const eq = diff ? ((u32)__builtin_ctzll(diff) >> 3) : 8;
+    bool const stop = fw ? eq < 8 : !((k < maxBack) && eq > 0);
+    u64 const sbal = wv_ballot(stop);
+    u64 const sf = sbal & 0xFFFFull, sk = sbal >> 48;
+    if (sf) { int const f = __builtin_ctzll(sf); *fwd = 8u * (u32)f + wv_readlane(eq, f); }
+    else *fwd = 128 + zsa_count_wave(R, ip + 128, m + 128, iend, lane);
+    if (sk) *bwd = (u32)__builtin_ctzll(sk);
+    else {
+        u32 nb = 16;
+        while (nb < maxBack) {   // zstd_fast.c:285-289, 64 bytes per step
+            u32 const kk = nb + (u32)lane;
+            bool const e = (kk < maxBack) && (zsa_rd8(R, ipB - 1 - kk) == zsa_rd8(R, mB - 1 - kk));
+            u64 const ne = wv_ballot(!e);
+            u32 const f = ne ? (u32)__builtin_ctzll(ne) : 64u;
+            nb += f;
+            if (f < 64) break;
+        }
+        *bwd = nb;
+    }
+}
 
 // Parses one block.  T: hash table (global and L2-resident, or LDS).  base: window base (index i <-> base + i, the frame starts at
 // index 2).  Returns the number of sequences appended to seqOut; rep[] and *lastLL are updated.  All values are wave-uniform.
@@ -199,7 +244,7 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, const TAB T, u32* ringWords, u
     // shows up as a common prefix shorter than 4 and the next event of the window is taken instead).
     bool const useFp = posBits != 0;
     u32 const posMask = useFp ? ((1u << posBits) - 1u) : 0xFFFFFFFFu;
-    u32 const fpShift = 32u - TAB::cellBits + posBits;     // the fingerprint fills the cell bits above the position
+    u32 const fpShift = posBits;                           // the fingerprint fills the cell bits above the position
 #ifdef ZSA_FP_TEST_BITS   // tests: a few fingerprint bits only, so that collisions are common
 #define ZSA_FPV(x) ((((u32)(x) * 2246822519U) >> fpShift) & ((1u << ZSA_FP_TEST_BITS) - 1u))
 #else
@@ -237,15 +282,30 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, const TAB T, u32* ringWords, u
     // The source words of the first window after a match are requested as soon as the match end is known, so that their
     // LDS round trip overlaps with the post-match table inserts instead of following them.
     u64 vPre = 0; bool havePre = false;
-    // ---- state of the hoisted window (TAB::lean, see the block at the top of the window loop)
-    u32 winB = 0; bool winOK = false;
-    u64 winH = 0, winC = 0;                                 // lanes whose probe is a fingerprint hit / whose cell another lane shares
-    u64 wv64 = 0; u32 whash = 0, wcell = 0, wcand = 0;      // per lane: source word, cell number, own cell value, probed position
-    u32 mOffA = 0, mOffB = 0; u64 mA = 0, mB = 0;           // repcode-compare masks of the window, by offset
+    // ---- state of the chunk path (TAB::filtered, see the block at the top of the window loop)
+    u32 winB = 0, winValid = 0;                             // chunk base; lanes [0, winValid) have exact probes (0: no chunk)
+    u64 winH = 0, ins = 0;                                  // lanes whose probe passes the filter / whose position entered the table (not yet written)
+    u64 wv64 = 0; u32 whash = 0, wcell = 0, wnib = 0;       // per lane: source word, cell number, own cell value, filter nibble at set-up
+    u32 mOffA = 0, mOffB = 0; u64 mA = 0, mB = 0;           // repcode-compare masks of the chunk, by offset
+    // writes the positions that entered the table since the chunk was set up.  Lanes below winValid fall into distinct
+    // cells that nothing else has written since; the few beyond it follow one by one, in position order (== time order)
+    auto commit = [&]() {
+        if (!TAB::filtered || !ins) return;
+        u64 const bulk = winValid >= 64 ? ins : (ins & ((1ull << winValid) - 1));
+        if ((bulk >> lane) & 1) { T.p[whash] = wcell; u32 const d = wnib ^ (wcell >> 28); if (d) T.fxor(whash, d); }
+        for (u64 t = ins & ~bulk; t; t &= t - 1) {
+            wv_lds_fence();
+            ZSA_STAT(7);
+            if (lane == __builtin_ctzll(t)) T.st(whash, wcell);
+        }
+        wv_lds_fence();
+        ins = 0;
+    };
     for (;;) {   // one search episode per iteration (label _start)
         u32 step = stepSize, nextStep = ip0 + 128, sNext = stepSize;
         if (ip0 + step + 1 >= ilimit) {
             // no room for a window: finish the immediate-repcode loop on its own
+            commit(); winValid = 0;
             while (chkRep2 && ip0 <= ilimit && zsa_ring32(R, ip0 - 2) == RD32(ip0 - rep2)) {
                 u32 const rLength = zsa_count_wave(R, ip0 + 4 - 2, ip0 + 4 - rep2 - 2, iend - 2, lane) + 4;
                 { u32 const t = rep2; rep2 = rep1; rep1 = t; }
@@ -265,185 +325,197 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, const TAB T, u32* ringWords, u
         }
         bool blockDone = false;
         for (;;) {   // one window per iteration
-            // the parse state is the same in every lane: keep it in scalar registers (see wv_uniform).  Measured: the hoisted
-            // window's scalar event pick needs it (-16 % launch time); the general evaluation alone is 2.5 % slower with it.
-            if (TAB::lean) {
+            // the parse state is the same in every lane: keep it in scalar registers (see wv_uniform): the chunk path's event
+            // pick is scalar bit arithmetic on ballots
+            if (TAB::filtered) {
                 ip0 = wv_uniform(ip0); anchor = wv_uniform(anchor); rep1 = wv_uniform(rep1); rep2 = wv_uniform(rep2);
                 nbSeq = wv_uniform(nbSeq); step = wv_uniform(step); sNext = wv_uniform(sNext); nextStep = wv_uniform(nextStep);
                 chkRep2 = wv_uniform_b(chkRep2); havePre = wv_uniform_b(havePre);
                 R.lo = wv_uniform(R.lo); R.hi = wv_uniform(R.hi);
-                winB = wv_uniform(winB); winOK = wv_uniform_b(winOK); winH = wv_uniform64(winH); winC = wv_uniform64(winC);
+                winB = wv_uniform(winB); winValid = wv_uniform(winValid); winH = wv_uniform64(winH); ins = wv_uniform64(ins);
                 mOffA = wv_uniform(mOffA); mOffB = wv_uniform(mOffB); mA = wv_uniform64(mA); mB = wv_uniform64(mB);
             }
             {   u32 const want = ip0 - 2 + 1024;
                 if (R.hi < want && R.hi < R.limit) zsa_ring_fill(R, want, lane);
             }
 
-            // ---- hoisted window (LDS-resident table).  While the step is 2 every position from ip0 on is visited, so the
-            // per-position work that does not depend on the parse state -- source word, hash, table probe, fingerprint
-            // compare -- is done once for 64 consecutive positions (lane k <-> position winB + k) and reused by every
-            // search that starts inside the window; what remains per sequence is a repcode compare (one mask per offset),
-            // a scalar pick of the first event in the reference's order and the match extension.  The probes stay exact as
-            // long as no cell that two lanes of the window share is written: such lanes are found when the window is set up
-            // (every lane leaves its position in its cell's low half, reads it back, restores it) and a step that would touch
-            // one is left to the general evaluation below, which reads the table afresh.
-            if (TAB::lean && useFp && stepSize == 2 && step == 2 && sNext == 2) {
-                if (!winOK || ip0 - winB > 59u) {
-                    ZSA_STAT(0);
-                    winB = ip0;
-                    u32 const q = winB + (u32)lane;
-                    wv64 = zsa_ring64(R, q - 2);
-                    whash = zsa_hashT<MLS>(wv64, hlog);
-                    u32 const fp = ZSA_FPV(wv64);
-                    wcell = (fp << posBits) | q;
-                    u32 const old = T.ld(whash);
-                    wcand = old & posMask;
-                    winH = wv_ballot(wcand >= prefixStartIndex && (old >> posBits) == fp);
-                    T.st16(whash, q);
-                    wv_lds_fence();
-                    u32 const rb = T.ld16(whash);
-                    wv_lds_fence();
-                    T.st16(whash, old);
-                    wv_lds_fence();
-                    u64 const losers = wv_ballot(rb != (q & 0xFFFFu));
-                    winC = losers;
-                    for (u64 m = losers; m; m &= m - 1) winC |= 1ull << ((wv_readlane(rb, __builtin_ctzll(m)) - winB) & 63u);
-                    mOffA = mOffB = 0; winOK = true;
-                }
-                u32 const o = ip0 - winB;
-                auto repMask = [&](u32 off) -> u64 {   // lanes whose 4 bytes equal the 4 bytes `off` before them
-                    if (off == mOffA) return mA;
-                    if (off == mOffB) return mB;
-                    u32 const q = winB + (u32)lane;
-                    u32 const a = q - 2 - off;
-                    u32 rv = zsa_ring32(R, a);                               // masked ring address, always legal
-                    if (ip0 - 2 - off < R.lo) {                              // uniform: older than the ring
-                        rv = ~(u32)wv64;
-                        if ((u32)lane >= o && q + 4 <= iend) rv = wv_ldg32_now(R.src + a);
-                    }
-                    u64 const m = wv_ballot(rv == (u32)wv64);
-                    mOffB = mOffA; mB = mA; mOffA = off; mA = m;
-                    return m;
-                };
-                if (chkRep2 && ((repMask(rep2) >> o) & 1)) {   // immediate repcode (zstd_fast.c:311-324)
-                    u32 const rLength = zsa_count_wave(R, ip0 + 4 - 2, ip0 + 4 - rep2 - 2, iend - 2, lane) + 4;
-                    { u32 const t = rep2; rep2 = rep1; rep1 = t; }
-                    ZSA_STAT(1);
-                    if ((u32)lane == o) T.st(whash, wcell);
-                    wv_lds_fence();
-                    if ((winC >> o) & 1) winOK = false;
-                    ip0 += rLength;
-                    if (lane == 0) seqStage[nbSeq & 63] = zsa_packseq(0, rLength - ZSA_MINMATCH, 1);
-                    nbSeq++;
-                    if ((nbSeq & 63) == 0) { wv_lds_fence(); seqOut[nbSeq - 64 + (u32)lane] = seqStage[lane]; wv_lds_fence(); }
-                    anchor = ip0;
-                    chkRep2 = (ip0 <= ilimit) && rep2 > 0;
-                    havePre = false;
-                    if (R.hi < ip0 - 2 + 512 && R.hi < R.limit) zsa_ring_fill(R, ip0 - 2 + 1024, lane);
-                    break;   // back to _start with the new ip0
-                }
-                // pairs (ip0 + 2i, ip0 + 2i + 1) that can be decided here: entered by the reference (`ip3 < ilimit`, :328), their
-                // repcode position ip0 + 2i + 2 inside the window, and no step increase before them (:322-327)
-                u32 const iE = (ilimit - ip0 - 2) >> 1;                      // ip0 + 3 < ilimit holds at the top of a window
-                u32 const nCov = (63u - o) >> 1;
+            // ---- chunk path.  While the step is 2 every position from ip0 on is visited, so the per-position work that does
+            // not depend on the parse state -- source word, hash, fingerprint, probe -- is done once for 64 consecutive
+            // positions (lane k <-> position winB + k) and reused by every search that starts inside the chunk.  The probe
+            // reads the LDS filter only; a lane whose filter nibble equals its fingerprint's MAY match.  What remains per
+            // sequence: a repcode compare (one mask per offset, cached), a scalar pick of the first event in the reference's
+            // order, ONE global cell read by the winning lane (position + full fingerprint), the match extension.  Positions
+            // that enter the table are collected in `ins` and written when the chunk is left (commit).
+            // Exactness: the probe of lane b is what the serial walk sees as long as no earlier lane of the chunk falls into
+            // the same cell (inserts happen in position order, so only earlier lanes can have written it since set-up).
+            // Set-up finds all lanes that share a cell with another one (a bitmap pass over the cell numbers); lanes below
+            // the second-lowest of them -- winValid -- are safe, and the chunk is set up again when the parse gets there.
+            if (TAB::filtered && useFp && stepSize == 2 && step == 2 && sNext == 2) {
+                u32 const iE = (ilimit - ip0 - 2) >> 1;                      // pairs the reference still enters (`ip3 < ilimit`, :328)
                 u32 const room = nextStep - ip0;
-                u32 const nStp = room > 4 ? (room - 3) >> 1 : 0;
-                u32 const n = iE < nCov ? (iE < nStp ? iE : nStp) : (nCov < nStp ? nCov : nStp);
+                u32 const nStp = room > 4 ? (room - 3) >> 1 : 0;             // pairs before the step grows (:322-327)
+                u32 const nES = iE < nStp ? iE : nStp;
+                // pairs (ip0 + 2i, ip0 + 2i + 1) the chunk covers: both lanes below winValid, the repcode lane ip0 + 2i + 2 <= 63
+                auto cover = [&](u32 o) -> u32 {
+                    if (o > 61 || o >= winValid) return 0;
+                    u32 const a = (63u - o) >> 1, b = (winValid - o) >> 1;
+                    return a < b ? a : b;
+                };
+                u32 o = ip0 - winB, n = 0;
+                if (nES) {
+                    if (winValid) n = cover(o);
+                    if (n == 0 && !(winValid && o == 0)) {
+                        commit();
+                        ZSA_STAT(0);
+                        winB = ip0; o = 0;
+                        u32 const q = winB + (u32)lane;
+                        wv64 = zsa_ring64(R, q - 2);
+                        whash = zsa_hashT<MLS>(wv64, hlog);
+                        wcell = (ZSA_FPV(wv64) << posBits) | q;
+                        wnib = T.fget(whash);
+                        winH = wv_ballot(wnib == (wcell >> 28));
+                        // lanes that share their cell with another lane: the first lane to reach a cell's bit finds it clear, the
+                        // others find it set and clear it again, which tells the first one
+                        u32* const dw = T.dupWord(whash);
+                        u32 const bit = 1u << (whash & 31u);
+                        bool const late = (wv_atomic_or_lds(dw, bit) & bit) != 0;
+                        wv_lds_fence();
+                        if (late) (void)wv_atomic_and_lds(dw, ~bit);
+                        wv_lds_fence();
+                        bool const shares = late || !(*dw & bit);
+                        wv_lds_fence();
+                        *dw = 0;
+                        wv_lds_fence();
+                        u64 const G = wv_ballot(shares);
+                        u64 const G2 = G & (G - 1);
+                        winValid = G2 ? (u32)__builtin_ctzll(G2) : 64u;
+                        if (winValid == 0) winValid = 1;   // (cannot happen: the second-lowest lane is at least 1)
+                        mOffA = mOffB = 0;
+                        n = cover(0);
+                    }
+                    if (n > nES) n = nES;
+                }
                 if (n) {
+                    auto repMask = [&](u32 off) -> u64 {   // lanes whose 4 bytes equal the 4 bytes `off` before them
+                        if (off == mOffA) return mA;
+                        if (off == mOffB) return mB;
+                        u32 const q = winB + (u32)lane;
+                        u32 const a = q - 2 - off;
+                        u32 rv = zsa_ring32(R, a);                               // masked ring address, always legal
+                        if (ip0 - 2 - off < R.lo) {                              // uniform: older than the ring
+                            rv = ~(u32)wv64;
+                            if ((u32)lane >= o && q + 4 <= iend) rv = wv_ldg32_now(R.src + a);
+                        }
+                        u64 const m = wv_ballot(rv == (u32)wv64);
+                        mOffB = mOffA; mB = mA; mOffA = off; mA = m;
+                        return m;
+                    };
+                    if (chkRep2 && ((repMask(rep2) >> o) & 1)) {   // immediate repcode (zstd_fast.c:311-324)
+                        u32 fwd, bwd;
+                        zsa_extend16(R, ip0 + 4 - 2, ip0 + 4 - rep2 - 2, iend - 2, ip0 - 2, ip0 - rep2 - 2, 0, &fwd, &bwd, lane);
+                        u32 const rLength = fwd + 4;
+                        { u32 const t = rep2; rep2 = rep1; rep1 = t; }
+                        ZSA_STAT(1);
+                        ins |= 1ull << o;
+                        ip0 += rLength;
+                        if (lane == 0) seqStage[nbSeq & 63] = zsa_packseq(0, rLength - ZSA_MINMATCH, 1);
+                        nbSeq++;
+                        if ((nbSeq & 63) == 0) { wv_lds_fence(); seqOut[nbSeq - 64 + (u32)lane] = seqStage[lane]; wv_lds_fence(); }
+                        anchor = ip0;
+                        chkRep2 = (ip0 <= ilimit) && rep2 > 0;
+                        havePre = false;
+                        if (R.hi < ip0 - 2 + 512 && R.hi < R.limit) zsa_ring_fill(R, ip0 - 2 + 1024, lane);
+                        break;   // back to _start with the new ip0
+                    }
                     u64 const R1 = rep1 ? repMask(rep1) : 0;
                     u64 const lowH = (1ull << (2 * n)) - 1;                  // n <= 31
                     u64 Hs = (winH >> o) & lowH;
                     u64 const Rs = (R1 >> o) & 0x5555555555555554ull & ((lowH << 1) | 1);
-                    u64 const Cs = winC >> o;
                     ZSA_PPROF(S, lane, 8);
                     int evRel = -1; u32 evRole = 0, evCand = 0, vFwd = 0, vBwd = 0;
-                    bool bail = false;
                     for (;;) {
                         // order of events: the repcode check at ip0 + 2i + 2 precedes the two table checks of pair i
                         u32 const fh = Hs ? (u32)__builtin_ctzll(Hs) : 64u, fr = Rs ? (u32)__builtin_ctzll(Rs) : 64u;
-                        if (fh == 64 && fr == 64) { bail = (Cs & lowH) != 0; break; }
-                        bool const repWins = fr != 64 && fr <= fh + 2;
-                        u32 const rel = repWins ? fr : fh;
-                        u32 const touched = repWins ? rel : rel + 2;
-                        if (Cs & ((1ull << touched) - 1)) { bail = true; break; }
-                        if (repWins) { evRel = (int)rel; evRole = 0; break; }
-                        u32 const cur = ip0 + rel, m = wv_readlane(wcand, (int)(o + rel));
-                        u32 const mb = (cur - anchor) < (m - prefixStartIndex) ? (cur - anchor) : (m - prefixStartIndex);
-                        zsa_extend_wave(R, cur - 2, m - 2, iend - 2, cur - 2, m - 2, mb, &vFwd, &vBwd, lane);
-                        if (vFwd >= 4) { evRel = (int)rel; evRole = 1 + (rel & 1); evCand = m; break; }
-                        winH &= ~(1ull << (o + rel)); Hs &= ~(1ull << rel);   // fingerprint collision: not an event
+                        if (fh == 64 && fr == 64) break;
+                        if (fr != 64 && fr <= fh + 2) { evRel = (int)fr; evRole = 0; break; }
+                        // the winning lane reads its cell: position, and the fingerprint bits the filter does not hold
+                        u32 const L = o + fh, cur = ip0 + fh;
+                        u32 x = 0;
+                        if ((u32)lane == L) x = T.ld(whash) ^ wcell;
+                        x = wv_readlane(x, (int)L);
+                        u32 const m = (x & posMask) ^ cur;
+                        if ((x >> posBits) == 0 && m >= prefixStartIndex) {
+                            u32 const mb = (cur - anchor) < (m - prefixStartIndex) ? (cur - anchor) : (m - prefixStartIndex);
+                            zsa_extend16(R, cur - 2, m - 2, iend - 2, cur - 2, m - 2, mb, &vFwd, &vBwd, lane);
+                            if (vFwd >= 4) { evRel = (int)fh; evRole = 1 + (fh & 1); evCand = m; break; }
+                        }
+                        ZSA_STAT(6);
+                        winH &= ~(1ull << L); Hs &= ~(1ull << fh);           // the filter let it through, the bytes differ: not an event
                     }
-                    if (!bail) {
-                        chkRep2 = false; havePre = false;
-                        ZSA_STAT(evRel < 0 ? 2 : 3);
-                        if (evRel < 0) {   // no event: all n pairs enter the table
-                            if ((u32)lane >= o && (u32)lane < o + 2 * n) T.st(whash, wcell);
+                    chkRep2 = false; havePre = false;
+                    ZSA_STAT(evRel < 0 ? 2 : 3);
+                    if (evRel < 0) {   // no event: all n pairs enter the table
+                        ins |= lowH << o;
+                        if (n == iE) { blockDone = true; break; }
+                        ip0 += 2 * n;
+                        continue;
+                    }
+                    // positions that enter the table (:266, :278, :300-303): up to the event's pair, plus the next pair's first
+                    // position when the second check hit (step <= 4)
+                    u32 const i2 = evRole == 0 ? (u32)evRel - 2 : ((u32)evRel & ~1u);
+                    u32 const cnt = evRole == 2 ? i2 + 3 : i2 + 2;
+                    ins |= ((1ull << cnt) - 1) << o;
+                    ZSA_PPROF(S, lane, 9);
+                    u32 current0, match0, mLength, offcode;
+                    if (evRole == 0) {
+                        current0 = ip0 + i2;
+                        ip0 = current0 + 2;
+                        match0 = ip0 - rep1;
+                        offcode = 1;
+                        u32 fwd, bwd;
+                        zsa_extend16(R, ip0 + 4 - 2, match0 + 4 - 2, iend - 2, ip0 - 2, match0 - 2, 1, &fwd, &bwd, lane);
+                        ip0 -= bwd; match0 -= bwd;
+                        mLength = 4 + bwd + fwd;
+                    } else {
+                        current0 = ip0 + (u32)evRel;
+                        ip0 = current0;
+                        match0 = evCand;
+                        rep2 = rep1;
+                        rep1 = ip0 - match0;
+                        offcode = rep1 + 3;
+                        ip0 -= vBwd; match0 -= vBwd;
+                        mLength = vBwd + vFwd;
+                    }
+                    if (lane == 0) seqStage[nbSeq & 63] = zsa_packseq(ip0 - anchor, mLength - ZSA_MINMATCH, offcode);
+                    nbSeq++;
+                    if ((nbSeq & 63) == 0) { wv_lds_fence(); seqOut[nbSeq - 64 + (u32)lane] = seqStage[lane]; wv_lds_fence(); }
+                    ip0 += mLength;
+                    anchor = ip0;
+                    if (ip0 <= ilimit) {
+                        if (R.hi < ip0 - 2 + 512 && R.hi < R.limit) zsa_ring_fill(R, ip0 - 2 + 1024, lane);
+                        u32 const pA = current0 + 2, pB = ip0 - 2;   // :307-309, in this order
+                        u32 const lA = pA - winB, lB = pB - winB;
+                        if (lB < 64) ins |= (1ull << lA) | (1ull << lB);
+                        else {   // the match left the chunk: write what is pending, then these two
+                            if (lA < 64) ins |= 1ull << lA;
+                            commit();
+                            u32 const pp = lane == 0 ? pA : pB;
+                            u32 hh = 0; u64 wd = 0;
+                            if (lane < 2) { wd = RD64(pp); hh = zsa_hashT<MLS>(wd, hlog); }
+                            if (lane == 0 && lA >= 64) T.st(hh, ZSA_CELL(pp, wd));
                             wv_lds_fence();
-                            if (n == iE) { blockDone = true; break; }
-                            ip0 += 2 * n;
-                            continue;
+                            if (lane == 1) T.st(hh, ZSA_CELL(pp, wd));
+                            wv_lds_fence();
+                            winValid = 0;
                         }
-                        // positions that stay in the table (:266, :278, :300-303): up to the event's pair, plus the next
-                        // pair's first position when the second check hit (step <= 4)
-                        u32 const i2 = evRole == 0 ? (u32)evRel - 2 : ((u32)evRel & ~1u);
-                        u32 const cnt = evRole == 2 ? i2 + 3 : i2 + 2;
-                        if ((u32)lane >= o && (u32)lane < o + cnt) T.st(whash, wcell);
-                        wv_lds_fence();
-                        ZSA_PPROF(S, lane, 9);
-                        u32 current0, match0, mLength, offcode;
-                        if (evRole == 0) {
-                            current0 = ip0 + i2;
-                            ip0 = current0 + 2;
-                            match0 = ip0 - rep1;
-                            offcode = 1;
-                            u32 fwd, bwd;
-                            zsa_extend_wave(R, ip0 + 4 - 2, match0 + 4 - 2, iend - 2, ip0 - 2, match0 - 2, 1, &fwd, &bwd, lane);
-                            ip0 -= bwd; match0 -= bwd;
-                            mLength = 4 + bwd + fwd;
-                        } else {
-                            current0 = ip0 + (u32)evRel;
-                            ip0 = current0;
-                            match0 = evCand;
-                            rep2 = rep1;
-                            rep1 = ip0 - match0;
-                            offcode = rep1 + 3;
-                            ip0 -= vBwd; match0 -= vBwd;
-                            mLength = vBwd + vFwd;
-                        }
-                        if (lane == 0) seqStage[nbSeq & 63] = zsa_packseq(ip0 - anchor, mLength - ZSA_MINMATCH, offcode);
-                        nbSeq++;
-                        if ((nbSeq & 63) == 0) { wv_lds_fence(); seqOut[nbSeq - 64 + (u32)lane] = seqStage[lane]; wv_lds_fence(); }
-                        ip0 += mLength;
-                        anchor = ip0;
-                        if (ip0 <= ilimit) {
-                            if (R.hi < ip0 - 2 + 512 && R.hi < R.limit) zsa_ring_fill(R, ip0 - 2 + 1024, lane);
-                            u32 const pA = current0 + 2, pB = ip0 - 2;   // :307-309, in this order
-                            u32 const lA = pA - winB, lB = pB - winB;
-                            if (lB < 64) {   // both inside the window: their cells are known
-                                if ((u32)lane == lA) T.st(whash, wcell);
-                                wv_lds_fence();
-                                if ((u32)lane == lB) T.st(whash, wcell);
-                                wv_lds_fence();
-                                if (((winC >> lA) | (winC >> lB)) & 1) winOK = false;
-                            } else {
-                                u32 const pp = lane == 0 ? pA : pB;
-                                u32 hh = 0; u64 wd = 0;
-                                if (lane < 2) { wd = RD64(pp); hh = zsa_hashT<MLS>(wd, hlog); }
-                                if (lane == 0) T.st(hh, ZSA_CELL(pp, wd));
-                                wv_lds_fence();
-                                if (lane == 1) T.st(hh, ZSA_CELL(pp, wd));
-                                wv_lds_fence();
-                                winOK = false;
-                            }
-                            chkRep2 = rep2 > 0;
-                        }
-                        ZSA_PPROF(S, lane, 10);
-                        break;   // goto _start
+                        chkRep2 = rep2 > 0;
                     }
+                    ZSA_PPROF(S, lane, 10);
+                    break;   // goto _start
                 }
-                ZSA_STAT(n ? 4 : 5);
-                winOK = false;   // the general evaluation below changes the table on its own
+                ZSA_STAT(nES ? 4 : 5);
             }
+            if (TAB::filtered) { commit(); winValid = 0; }   // the general evaluation below reads and writes the table itself
             // ---- positions of this window: P_0 = ip0, P_{i+1} = P_i + s_i, s_{i+1} = step at that time (zstd_fast.c:316-327).
             // pos = the position this lane looks at: P_pair (+1) for the hash lanes, P_{pair+1} for the repcode lane.
             bool const fast = (step == 2) & (sNext == 2) & (ip0 + 2 + ZSA_NP * 2 < nextStep);
@@ -487,6 +559,7 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, const TAB T, u32* ringWords, u
             }
             wv_lds_fence();
             u32 const back = (valid && hashLane) ? tags[h & (ZSA_NTAGS - 1)] : (u32)lane;
+            if (TAB::filtered && valid && hashLane) tags[h & (ZSA_NTAGS - 1)] = 0;   // (the tags double as the chunk path's bitmap: all zero between uses)
             bool const shared = wv_ballot(back != (u32)lane) != 0;
             u64 const vm = wv_ballot(valid && hashLane);
             u32 cmpIdx = old & posMask, cmpFp = useFp ? old >> posBits : 0;
@@ -646,6 +719,7 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, const TAB T, u32* ringWords, u
 #undef RD8
 #undef ZSA_FPV
 #undef ZSA_CELL
+    commit();
     {   u32 const n = nbSeq & 63;
         wv_lds_fence();
         if ((u32)lane < n) seqOut[nbSeq - n + (u32)lane] = seqStage[lane];
@@ -675,4 +749,12 @@ ZSA_DEV u32 zsa_parse_fast_wave(ZsaEncShared* S, u32* T, u32* ringWords, u64* se
 {
     ZsaTabGlobal tab; tab.p = T;
     return zsa_parse_fast_wave_tab<ZsaTabGlobal>(S, tab, ringWords, seqStage, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
+}
+// chunk path: `filt` = (1 << hashLog) / 8 words of LDS holding the top 4 bits of every cell, `dup` = (1 << hashLog) / 32 words, all zero
+// (it doubles as the general evaluation's tag array, which needs ZSA_NTAGS bytes)
+ZSA_DEV u32 zsa_parse_fast_wave_filt(ZsaEncShared* S, u32* T, u32* filt, u32* dup, u32* ringWords, u64* seqStage, const ZsaEncParams& P, const u8* base, u32 dictLimit,
+                                     const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL, u32 posBits, int lane)
+{
+    ZsaTabFilt tab; tab.p = T; tab.filt = filt; tab.dup = dup;
+    return zsa_parse_fast_wave_tab<ZsaTabFilt>(S, tab, ringWords, seqStage, (u8*)dup, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
 }

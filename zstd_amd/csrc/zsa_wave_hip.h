@@ -60,6 +60,8 @@ ZSA_DEV unsigned long long wv_clock() { return (unsigned long long)clock64(); }
 ZSA_DEV unsigned wv_atomic_add_lds(unsigned* p, unsigned v) { return atomicAdd(p, v); }
 ZSA_DEV unsigned wv_atomic_or_lds(unsigned* p, unsigned v) { return atomicOr(p, v); }
 ZSA_DEV unsigned wv_atomic_max_lds(unsigned* p, unsigned v) { return atomicMax(p, v); }
+ZSA_DEV unsigned wv_atomic_xor_lds(unsigned* p, unsigned v) { return atomicXor(p, v); }
+ZSA_DEV unsigned wv_atomic_and_lds(unsigned* p, unsigned v) { return atomicAnd(p, v); }
 ZSA_DEV unsigned wv_atomic_add_global(unsigned* p, unsigned v) { return atomicAdd(p, v); }
 ZSA_DEV void wv_atomic_max_global(unsigned* p, unsigned v) { (void)atomicMax(p, v); }
 // device-scope fence: afterwards plain loads of this wave observe earlier device-scope atomics (they bypass the L1)
