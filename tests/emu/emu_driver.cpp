@@ -75,7 +75,8 @@ struct EncArgs { ZsaEncShared* S; u32* ht; ZsaEncParams P; const u8* src; u64 sr
 static void enc_entry(void* a)
 {
     EncArgs* A = (EncArgs*)a;
-    u64 r = A->P.strat >= 3 ? zsa_encode_frame<1>(A->S, A->ht, A->P, A->src, A->srcSize, A->dst, A->cap, A->W, A->cd, A->dictMode)
+    u64 r = (A->P.strat == 1 && !A->cd) ? zsa_encode_frame<2>(A->S, A->ht, A->P, A->src, A->srcSize, A->dst, A->cap, A->W, nullptr, 0)
+          : A->P.strat >= 3 ? zsa_encode_frame<1>(A->S, A->ht, A->P, A->src, A->srcSize, A->dst, A->cap, A->W, A->cd, A->dictMode)
                             : zsa_encode_frame<0>(A->S, A->ht, A->P, A->src, A->srcSize, A->dst, A->cap, A->W, A->cd, A->dictMode);
     if (wv_lane() == 0) A->result = r;
 }

@@ -87,6 +87,7 @@ ZSA_DEV unsigned long long wv_ldg64(const unsigned char* p) { unsigned long long
 ZSA_DEV unsigned wv_vzero() { return 0; }
 ZSA_DEV unsigned wv_ldg_cell(const unsigned* p) { return *p; }
 ZSA_DEV void wv_stg_cell(unsigned* p, unsigned v) { *p = v; }
+ZSA_DEV void wv_stg64(void* p, unsigned long long v) { *(unsigned long long*)p = v; }
 ZSA_DEV void wv_stg8(unsigned char* p, unsigned v) { *p = (unsigned char)v; }
 ZSA_DEV unsigned wv_ldg8_now(const unsigned char* p) { return wv_ldg8(p); }
 ZSA_DEV unsigned wv_ldg32_now(const unsigned char* p) { return wv_ldg32(p); }

@@ -85,9 +85,8 @@ struct ZsaEncShared {
                 struct { u32 bLit[64], bSrc[64]; };   // literal gather
             };
         };
-        struct {   // parse stage (zsa_parse.h): source ring + sequence staging + filter + cell bitmap / shared-cell tags
+        struct {   // parse stage (zsa_parse.h): source ring + filter + cell bitmap / shared-cell tags
             u32 ring[ZSA_RING_BYTES / 4 + 4];
-            u64 seqStage[64];
             u32 filt[(1u << ZSA_FILT_HLOG_MAX) / 8];
             union { u32 dupBits[(1u << ZSA_FILT_HLOG_MAX) / 32]; u8 tags[ZSA_NTAGS]; };
         };
@@ -1575,8 +1574,9 @@ ZSA_DEV void zsa_gatherLiterals(ZsaEncShared* S, const u64* seq, u32 nbSeq, cons
 // Returns bytes written or (u64)-error (uniform).
 struct ZsaEncScratch { u64* seq; u8* lit; u8* tmp; ZsaFseCT* park; };   // park: 3 sequence tables (LL, OF, ML) of the last compressed block
 
-// FAMILY 0: ZSTD_fast / ZSTD_dfast (and the dictionary variants); FAMILY 1: ZSTD_greedy / ZSTD_lazy / ZSTD_lazy2.  Each is
-// compiled into a kernel of its own: each parser then gets the whole register budget (one kernel holding both spilled).
+// FAMILY 0: ZSTD_dfast, and ZSTD_fast with a dictionary; FAMILY 1: ZSTD_greedy / ZSTD_lazy / ZSTD_lazy2; FAMILY 2: ZSTD_fast
+// without a dictionary (levels 1, 2 and below: the headline path).  Each is compiled into a kernel of its own: each parser
+// then gets the whole register budget (one kernel holding two of them spilled).
 template <int FAMILY>
 ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams& P, const u8* src, u64 srcSize64,
                              u8* dst, u64 dstCapacity, const ZsaEncScratch& W, const ZsaCDictDev* cd, int dictMode)
@@ -1684,7 +1684,7 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
     u32 fpPosBits = 0;
     if (!cd && P.strat == 1) { u32 const bits = 32u - (u32)__builtin_clz(srcSize + 2u); if (bits <= 26u) fpPosBits = bits; }
     // chunk path (zsa_parse.h): levels 1-2 (step 2) with a table the LDS filter covers
-    bool const chunkParse = FAMILY == 0 && fpPosBits != 0 && P.tlen <= 1 && P.hlog <= ZSA_FILT_HLOG_MAX;
+    bool const chunkParse = FAMILY == 2 && fpPosBits != 0 && P.tlen <= 1 && P.hlog <= ZSA_FILT_HLOG_MAX;
     int const literalsDisabled = (P.strat == 1) && (P.tlen > 0);   // zstd_compress_internal.h:605-618
     u32 const maxDist = 1u << P.wlog;
     ZsaLazyCtx LZ;   // greedy / lazy / lazy2 (zsa_lazy.h): match-finder state that lives across the blocks of the frame
@@ -1743,12 +1743,12 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
                 u32 lastLL = 0, nbSeq;
                 if (FAMILY == 1) {   // greedy / lazy / lazy2 (never with a dictionary here): wave-uniform, zsa_lazy.h
                     nbSeq = zsa_parse_lazy(LZ, Wn.dictLimit, ip, blockSize, P.strat - 3, rep, W.seq, &lastLL, lane);
-                } else if (P.strat == 2) {   // ZSTD_dfast (never with a dictionary here): serial for now, zsa_dfast.h
+                } else if (FAMILY == 0 && P.strat == 2) {   // ZSTD_dfast (never with a dictionary here): serial for now, zsa_dfast.h
                     nbSeq = 0;
                     if (lane == 0) nbSeq = zsa_parse_dfast(hashTable, hashTable + (1u << P.hlog), P, Wn.base, Wn.dictLimit, ip, blockSize, rep, W.seq, &lastLL);
                     nbSeq = wv_shfl(nbSeq, 0); lastLL = wv_shfl(lastLL, 0);
                     rep[0] = wv_shfl(rep[0], 0); rep[1] = wv_shfl(rep[1], 0);
-                } else if (Wn.loadedDictEnd != 0) {   // contiguous-dictionary corner (extDict too small): serial plain parser
+                } else if (FAMILY == 0 && Wn.loadedDictEnd != 0) {   // contiguous-dictionary corner (extDict too small): serial plain parser
                     nbSeq = 0;
                     if (lane == 0) nbSeq = zsa_parse_fast(hashTable, P, Wn.base, Wn.dictLimit, Wn.loadedDictEnd, ip, blockSize, rep, W.seq, &lastLL);
                     nbSeq = wv_shfl(nbSeq, 0); lastLL = wv_shfl(lastLL, 0);
@@ -1770,9 +1770,9 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
                         }
                         for (u32 i = (u32)lane; i < sizeof(S->dupBits) / 4; i += ZSA_WAVE) S->dupBits[i] = 0;
                         wv_sync();
-                        nbSeq = zsa_parse_fast_wave_filt(S, hashTable, S->filt, S->dupBits, S->ring, S->seqStage, P, Wn.base, Wn.dictLimit, ip, blockSize, rep, W.seq, &lastLL, fpPosBits, lane);
+                        nbSeq = zsa_parse_fast_block(hashTable, S->filt, S->dupBits, S->ring, S->tags, P, Wn.base, Wn.dictLimit, ip, blockSize, rep, W.seq, &lastLL, fpPosBits, lane);
                     } else {
-                        nbSeq = zsa_parse_fast_wave(S, hashTable, S->ring, S->seqStage, S->tags, P, Wn.base, Wn.dictLimit, ip, blockSize, rep, W.seq, &lastLL, fpPosBits, lane);
+                        nbSeq = zsa_parse_fast_block(hashTable, nullptr, nullptr, S->ring, S->tags, P, Wn.base, Wn.dictLimit, ip, blockSize, rep, W.seq, &lastLL, fpPosBits, lane);
                     }
                     wv_sync();
                     for (u32 i = (u32)lane; i < sizeof(ZsaHufCT) / 4; i += ZSA_WAVE) ((u32*)&S->hufPrev)[i] = park[i];
@@ -1785,6 +1785,9 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
             }
             wv_sync();
             ZSA_PROF(S, lane, 1);
+#ifdef ZSA_BISECT_PARSE_ONLY   // diagnostics: instruction counts of the parse alone
+            return 100;
+#endif
             u32 const nbSeq = S->u[EU_nbSeq], lastLL = S->u[EU_lastLL];
             // literal bytes = block bytes not covered by matches
             u32 litSize;
@@ -1796,7 +1799,7 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
             wv_sync();
             ZSA_PROF(S, lane, 2);
             // (FAMILY 0: the strategy is 1 or 2, which folds the cost-based mode selection out of that kernel)
-            u32 const strat = FAMILY == 0 ? (P.strat == 2 ? 2u : 1u) : P.strat;
+            u32 const strat = FAMILY == 2 ? 1u : (FAMILY == 0 ? (P.strat == 2 ? 2u : 1u) : P.strat);
             cSize = zsa_entropyCompress(S, W.seq, nbSeq, W.lit, litSize, op + 3, blockSize, W.tmp, literalsDisabled, cd, strat,
                                         (FAMILY == 1 && P.strat >= 4 && !cd) ? W.park : (const ZsaFseCT*)0, lane);
             if (S->err) return ZSA_ERR(S->err);

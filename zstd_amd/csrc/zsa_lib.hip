@@ -73,14 +73,14 @@ zsa_k_decompress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ resu
     if (prof && threadIdx.x == 0) for (int i = 0; i < ZSA_NPROF; i++) atomicAdd((unsigned long long*)&prof[i], (unsigned long long)S.prof[i]);
 }
 
-// One persistent compress kernel per parser family (zsa_encode.h).  A launch at level 4 needs both (clevels.h mixes
-// ZSTD_dfast and ZSTD_greedy rows there, chosen per frame by its size): each kernel then walks all frames with a counter of
-// its own and takes the ones of its family; `reportUnsupported` says which of the two writes the error word of a frame
-// neither can take (0: not this one, 1: this one, 2: this one, and it is the only launch).
+// One persistent compress kernel per parser family (zsa_encode.h).  A launch runs the kernels of the families its level can
+// resolve to (clevels.h chooses the strategy per frame by its size: level 2 mixes ZSTD_fast and ZSTD_dfast rows, level 4
+// ZSTD_dfast and ZSTD_greedy): each kernel then walks all frames with a counter of its own and takes the ones of its family.
+// `famMask` = families launched; the kernel with `reporter` set writes the error word of a frame none of them can take.
 template <int FAMILY>
 ZSA_DEV void zsa_compress_body(ZsaEncShared& S, u32& nextFrame, const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
                                u32* __restrict__ counter, u8* __restrict__ scratch, const ZsaEncLayout L, int level, const ZsaCDictDev* cd,
-                               int reportUnsupported, u64* __restrict__ prof)
+                               int famMask, int reporter, u64* __restrict__ prof)
 {
     if (threadIdx.x == 0) { for (int i = 0; i < ZSA_NPROF; i++) S.prof[i] = 0; S.profLast = wv_clock(); }
     u8* const wg = scratch + (size_t)blockIdx.x * L.stride;
@@ -105,14 +105,13 @@ ZSA_DEV void zsa_compress_body(ZsaEncShared& S, u32& nextFrame, const ZsaFrameDe
         // (a frame larger than the launch was sized for -- sizes linked on the device -- is refused rather than overrun)
         bool const unsupported = bad || !(cp.strat == 1 || (cp.strat >= 2 && cp.strat <= 5 && !cd)) || tableBytes > L.htBytes
                               || (d.srcSize > L.blockCap && L.blockCap < ZSA_BLOCKSIZE_MAX);
-        if (unsupported) {
-            if (reportUnsupported && threadIdx.x == 0) results[f] = ZSA_ERR(ZSA_parameter_unsupported);
-        } else if ((cp.strat >= 3) == (FAMILY == 1)) {
+        int const fam = cd ? 0 : (cp.strat == 1 ? 2 : (cp.strat == 2 ? 0 : 1));
+        if (unsupported || !((famMask >> fam) & 1)) {
+            if (reporter && threadIdx.x == 0) results[f] = ZSA_ERR(ZSA_parameter_unsupported);
+        } else if (fam == FAMILY) {
             ZsaEncParams P; P.wlog = cp.wlog; P.hlog = cp.hlog; P.mml = cp.mml; P.tlen = cp.tlen; P.clog = cp.clog; P.strat = cp.strat; P.slog = cp.slog;
-            u64 const r = zsa_encode_frame<FAMILY>(&S, zsa_hashTable, P, d.src, d.srcSize, d.dst, d.dstCapacity, W, cd, dictMode);
+            u64 const r = zsa_encode_frame<FAMILY>(&S, zsa_hashTable, P, d.src, d.srcSize, d.dst, d.dstCapacity, W, FAMILY == 0 ? cd : (const ZsaCDictDev*)nullptr, dictMode);
             if (threadIdx.x == 0) results[f] = r;
-        } else if (reportUnsupported == 2) {   // the only launch, and the frame is not of its family: no row of clevels.h does that
-            if (threadIdx.x == 0) results[f] = ZSA_ERR(ZSA_parameter_unsupported);
         }
         __syncthreads();
     }
@@ -121,21 +120,30 @@ ZSA_DEV void zsa_compress_body(ZsaEncShared& S, u32& nextFrame, const ZsaFrameDe
 
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZSA_ENC_WAVES, ZSA_ENC_WAVES)))
 zsa_k_compress(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
-               u32* __restrict__ counter, u8* __restrict__ scratch, const ZsaEncLayout L, int level, const ZsaCDictDev* cd, int reportUnsupported,
+               u32* __restrict__ counter, u8* __restrict__ scratch, const ZsaEncLayout L, int level, int famMask, int reporter,
                u64* __restrict__ prof)
-{
+{   // ZSTD_fast without a dictionary: the wave parser with the chunk path (zsa_parse.h)
     __shared__ ZsaEncShared S;
     __shared__ u32 nextFrame;
-    zsa_compress_body<0>(S, nextFrame, frames, results, nFrames, counter, scratch, L, level, cd, reportUnsupported, prof);
+    zsa_compress_body<2>(S, nextFrame, frames, results, nFrames, counter, scratch, L, level, nullptr, famMask, reporter, prof);
+}
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZSA_ENC_WAVES, ZSA_ENC_WAVES)))
+zsa_k_compress_dict(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
+                    u32* __restrict__ counter, u8* __restrict__ scratch, const ZsaEncLayout L, int level, const ZsaCDictDev* cd, int famMask, int reporter,
+                    u64* __restrict__ prof)
+{   // ZSTD_dfast, and ZSTD_fast with a dictionary
+    __shared__ ZsaEncShared S;
+    __shared__ u32 nextFrame;
+    zsa_compress_body<0>(S, nextFrame, frames, results, nFrames, counter, scratch, L, level, cd, famMask, reporter, prof);
 }
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZSA_ENC_WAVES, ZSA_ENC_WAVES)))
 zsa_k_compress_lazy(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
-                    u32* __restrict__ counter, u8* __restrict__ scratch, const ZsaEncLayout L, int level, const ZsaCDictDev* cd, int reportUnsupported,
+                    u32* __restrict__ counter, u8* __restrict__ scratch, const ZsaEncLayout L, int level, int famMask, int reporter,
                     u64* __restrict__ prof)
-{
+{   // ZSTD_greedy / ZSTD_lazy / ZSTD_lazy2
     __shared__ ZsaEncShared S;
     __shared__ u32 nextFrame;
-    zsa_compress_body<1>(S, nextFrame, frames, results, nFrames, counter, scratch, L, level, cd, reportUnsupported, prof);
+    zsa_compress_body<1>(S, nextFrame, frames, results, nFrames, counter, scratch, L, level, nullptr, famMask, reporter, prof);
 }
 
 __global__ void zsa_k_link_sizes(ZsaFrameDesc* __restrict__ frames, const u64* __restrict__ results, u32 n)
@@ -411,17 +419,28 @@ extern "C" size_t zsa_compress_enqueue(zsa_batch* b, int level, const zsa_CDict*
         }
     }
     HIPCHK(hipMemsetAsync(b->d_counter, 0, 256, (hipStream_t)stream));
-    // which parser families the level's clevels.h rows need: ZSTD_fast/ZSTD_dfast up to level 4 (and with a dictionary),
-    // ZSTD_greedy/ZSTD_lazy/ZSTD_lazy2 from level 4 on
-    bool const fam0 = cdict || level <= 4, fam1 = !cdict && level >= 4;
+    // which parser families the level's clevels.h rows can resolve to: a dictionary -> family 0; ZSTD_fast at levels <= 2
+    // (level 0 means 3); ZSTD_dfast at levels 2-4; ZSTD_greedy/ZSTD_lazy/ZSTD_lazy2 from level 4 on
+    int const lv = level == 0 ? 3 : level;
+    bool const fam2 = !cdict && lv <= 2, fam0 = cdict || (lv >= 2 && lv <= 4), fam1 = !cdict && lv >= 4;
+    int const famMask = (fam0 ? 1 : 0) | (fam1 ? 2 : 0) | (fam2 ? 4 : 0);
     const ZsaCDictDev* const cd = cdict ? (const ZsaCDictDev*)cdict->d_cd : (const ZsaCDictDev*)nullptr;
     u64* const prof = b->profOn ? b->d_prof : (u64*)nullptr;
-    if (fam0)
+    // (same scratch: the launches run one after the other on the stream; the first one reports unsupported frames)
+    int reporter = 1;
+    if (fam2) {
         hipLaunchKernelGGL(zsa_k_compress, dim3(grid), dim3(64), 0, (hipStream_t)stream,
-                           b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter, b->d_encScratch, L, level, cd, fam1 ? 1 : 2, prof);
-    if (fam1)   // same scratch: the two launches run one after the other on the stream
+                           b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter + 32, b->d_encScratch, L, level, famMask, reporter, prof);
+        reporter = 0;
+    }
+    if (fam0) {
+        hipLaunchKernelGGL(zsa_k_compress_dict, dim3(grid), dim3(64), 0, (hipStream_t)stream,
+                           b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter, b->d_encScratch, L, level, cd, famMask, reporter, prof);
+        reporter = 0;
+    }
+    if (fam1)
         hipLaunchKernelGGL(zsa_k_compress_lazy, dim3(grid), dim3(64), 0, (hipStream_t)stream,
-                           b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter + 16, b->d_encScratch, L, level, cd, fam0 ? 0 : 2, prof);
+                           b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter + 16, b->d_encScratch, L, level, famMask, reporter, prof);
     HIPCHK(hipGetLastError());
     b->lastWG = grid; b->lastLDS = (unsigned)ldsPerWG;
     return 0;

@@ -186,11 +186,11 @@ struct ZsaTabGlobal {   // one 32-bit word per cell in the workgroup's global sc
 struct ZsaTabFilt {
     u32* p; u32* filt; u32* dup;
     static constexpr bool filtered = true;
-    ZSA_MEM u32 ld(u32 h) const { return p[h]; }
+    ZSA_MEM u32 ld(u32 h) const { return wv_ldg_cell(p + h); }
     ZSA_MEM u32 fget(u32 h) const { return (filt[h >> 3] >> ((h & 7u) * 4u)) & 15u; }
     // d = old nibble ^ new nibble.  An atomic xor: lanes that update different cells of one word do not disturb each other
     ZSA_MEM void fxor(u32 h, u32 d) const { (void)wv_atomic_xor_lds(&filt[h >> 3], d << ((h & 7u) * 4u)); }
-    ZSA_MEM void st(u32 h, u32 c) const { p[h] = c; u32 const d = fget(h) ^ (c >> 28); if (d) fxor(h, d); }
+    ZSA_MEM void st(u32 h, u32 c) const { wv_stg_cell(p + h, c); u32 const d = fget(h) ^ (c >> 28); if (d) fxor(h, d); }
     ZSA_MEM u32* dupWord(u32 h) const { return &dup[h >> 5]; }
 };
 
@@ -229,47 +229,50 @@ ZSA_DEV void zsa_extend16(const ZsaRing& R, u32 ip, u32 m, u32 iend, u32 ipB, u3
     }
 }
 
-// Parses one block.  T: hash table (global and L2-resident, or LDS).  base: window base (index i <-> base + i, the frame starts at
-// index 2).  Returns the number of sequences appended to seqOut; rep[] and *lastLL are updated.  All values are wave-uniform.
-template <int MLS, class TAB>
-ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, const TAB T, u32* ringWords, u64* seqStage, u8* tags, const ZsaEncParams& P, const u8* base, u32 dictLimit,
-                                 const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL, u32 posBits, int lane)
-{
-    u32 const hlog = P.hlog;
-    // Table cells.  posBits == 0: a cell is the position, as in the reference.  posBits > 0 (frames without a dictionary,
-    // whose table only this parser touches): the low posBits bits are the position and the bits above them a fingerprint
-    // of the 4 bytes at that position.  A probe whose fingerprint differs from the current 4 bytes cannot match, so only
-    // the event that wins the window ever reads its candidate's bytes -- and that read is the first round of the match
-    // extension, which then starts at byte 0 and doubles as the 4-byte check the reference makes (a fingerprint collision
-    // shows up as a common prefix shorter than 4 and the next event of the window is taken instead).
-    bool const useFp = posBits != 0;
-    u32 const posMask = useFp ? ((1u << posBits) - 1u) : 0xFFFFFFFFu;
-    u32 const fpShift = posBits;                           // the fingerprint fills the cell bits above the position
+// ---- what a block's parse carries from one function to the next (all wave-uniform)
+struct ZsaParseCtx {      // constants of the block
+    const u8* base; u64* seqOut;
+    u32 hlog, posBits, stepSize, iend, ilimit, prefixStartIndex;
+};
+struct ZsaParseState {
+    u32 ip0, anchor, rep1, rep2, nbSeq;
+    u32 chkRep2;          // the immediate-repcode check at ip0 (zstd_fast.c:311-324) is still to be made
+    u32 nextStep;         // midEpisode: the search that is under way raises its step at this position (:322-327)
+    u32 midEpisode;
+    u32 rlo, rhi;         // what the source ring holds
+    u32 done;             // the block is parsed
+};
 #ifdef ZSA_FP_TEST_BITS   // tests: a few fingerprint bits only, so that collisions are common
-#define ZSA_FPV(x) ((((u32)(x) * 2246822519U) >> fpShift) & ((1u << ZSA_FP_TEST_BITS) - 1u))
+#define ZSA_FPV(x) ((((u32)(x) * 2246822519U) >> posBits) & ((1u << ZSA_FP_TEST_BITS) - 1u))
 #else
-#define ZSA_FPV(x) (((u32)(x) * 2246822519U) >> fpShift)
+#define ZSA_FPV(x) (((u32)(x) * 2246822519U) >> posBits)
 #endif
 #define ZSA_CELL(p, x) (useFp ? ((ZSA_FPV(x) << posBits) | (p)) : (p))
-    u32 const stepSize = (P.tlen > 1) ? (P.tlen + 1) : 2;      // zstd_fast.c:153, :429
-    u32 const istart = (u32)(src - base), iend = istart + srcSize, ilimit = iend - 8;   // indices
-    u32 const maxDistance = 1u << P.wlog;
-    // ZSTD_getLowestPrefixIndex (zstd_compress_internal.h:1307-1318), no loaded dictionary
-    u32 const prefixStartIndex = (iend - dictLimit > maxDistance) ? iend - maxDistance : dictLimit;
-    ZsaRing R;
-    R.b = (u8*)ringWords; R.src = base + 2; R.limit = iend - 2; R.lo = R.hi = (istart - 2) & ~1023u;
 #define RD32(i) zsa_rd32(R, (i) - 2)
 #define RD64(i) zsa_rd64(R, (i) - 2)
 #define RD8(i)  zsa_rd8(R, (i) - 2)
-    u32 anchor = istart, ip0 = istart;
-    u32 rep1 = rep[0], rep2 = rep[1], saved1 = 0, saved2 = 0, nbSeq = 0;
-    ip0 += (ip0 == prefixStartIndex);
-    {   u32 const curr = ip0;
-        u32 const windowLow = (curr - dictLimit > maxDistance) ? curr - maxDistance : dictLimit;
-        u32 const maxRep = curr - windowLow;
-        if (rep2 > maxRep) { saved2 = rep2; rep2 = 0; }
-        if (rep1 > maxRep) { saved1 = rep1; rep1 = 0; }
-    }
+
+// The general window evaluation.  Runs from st.ip0 to the end of the block, or -- `until` != 0xFFFFFFFF -- hands back at the
+// first search restart (label _start of the reference) at or beyond position `until`.
+// Table cells.  posBits == 0: a cell is the position, as in the reference.  posBits > 0 (frames without a dictionary,
+// whose table only this parser touches): the low posBits bits are the position and the bits above them a fingerprint
+// of the 4 bytes at that position.  A probe whose fingerprint differs from the current 4 bytes cannot match, so only
+// the event that wins the window ever reads its candidate's bytes -- and that read is the first round of the match
+// extension, which then starts at byte 0 and doubles as the 4-byte check the reference makes (a fingerprint collision
+// shows up as a common prefix shorter than 4 and the next event of the window is taken instead).
+template <int MLS, class TAB>
+ZSA_DEV void zsa_parse_general_body(const TAB T, u32* ringWords, u8* tags, const ZsaParseCtx& C, ZsaParseState& st, u32 until, int lane)
+{
+    u32 const hlog = C.hlog, posBits = C.posBits, stepSize = C.stepSize, iend = C.iend, ilimit = C.ilimit, prefixStartIndex = C.prefixStartIndex;
+    u64* const seqOut = C.seqOut;
+    bool const useFp = posBits != 0;
+    u32 const posMask = useFp ? ((1u << posBits) - 1u) : 0xFFFFFFFFu;
+    ZsaRing R;
+    R.b = (u8*)ringWords; R.src = C.base + 2; R.limit = iend - 2; R.lo = wv_uniform(st.rlo); R.hi = wv_uniform(st.rhi);
+    u32 anchor = wv_uniform(st.anchor), ip0 = wv_uniform(st.ip0);
+    u32 rep1 = wv_uniform(st.rep1), rep2 = wv_uniform(st.rep2), nbSeq = wv_uniform(st.nbSeq);
+    bool resume = wv_uniform(st.midEpisode) != 0;
+    u32 const resumeNext = wv_uniform(st.nextStep);
     u32 const pair = (u32)lane / 3u, role = (u32)lane - 3u * pair;   // role 0: repcode check, 1: hash ip0, 2: hash ip0+1
     bool const inWin = lane < 3 * ZSA_NP;
     bool const hashLane = inWin && role != 0;
@@ -278,34 +281,18 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, const TAB T, u32* ringWords, u
 
     // The immediate-repcode check that follows every match (zstd_fast.c:311-324) rides along with the next window as one
     // more event (lane 63) that precedes all others: its compare shares the window's memory round trip.
-    bool chkRep2 = false;
+    bool chkRep2 = wv_uniform(st.chkRep2) != 0;
     // The source words of the first window after a match are requested as soon as the match end is known, so that their
     // LDS round trip overlaps with the post-match table inserts instead of following them.
     u64 vPre = 0; bool havePre = false;
-    // ---- state of the chunk path (TAB::filtered, see the block at the top of the window loop)
-    u32 winB = 0, winValid = 0;                             // chunk base; lanes [0, winValid) have exact probes (0: no chunk)
-    u64 winH = 0, ins = 0;                                  // lanes whose probe passes the filter / whose position entered the table (not yet written)
-    u64 wv64 = 0; u32 whash = 0, wcell = 0, wnib = 0;       // per lane: source word, cell number, own cell value, filter nibble at set-up
-    u32 mOffA = 0, mOffB = 0; u64 mA = 0, mB = 0;           // repcode-compare masks of the chunk, by offset
-    // writes the positions that entered the table since the chunk was set up.  Lanes below winValid fall into distinct
-    // cells that nothing else has written since; the few beyond it follow one by one, in position order (== time order)
-    auto commit = [&]() {
-        if (!TAB::filtered || !ins) return;
-        u64 const bulk = winValid >= 64 ? ins : (ins & ((1ull << winValid) - 1));
-        if ((bulk >> lane) & 1) { T.p[whash] = wcell; u32 const d = wnib ^ (wcell >> 28); if (d) T.fxor(whash, d); }
-        for (u64 t = ins & ~bulk; t; t &= t - 1) {
-            wv_lds_fence();
-            ZSA_STAT(7);
-            if (lane == __builtin_ctzll(t)) T.st(whash, wcell);
-        }
-        wv_lds_fence();
-        ins = 0;
-    };
+    bool blockDone = false, first = true;
     for (;;) {   // one search episode per iteration (label _start)
+        if (!first && ip0 >= until) break;                       // hand back at a search restart (after at least one search)
+        first = false;
         u32 step = stepSize, nextStep = ip0 + 128, sNext = stepSize;
+        if (resume) { nextStep = resumeNext; resume = false; }
         if (ip0 + step + 1 >= ilimit) {
             // no room for a window: finish the immediate-repcode loop on its own
-            commit(); winValid = 0;
             while (chkRep2 && ip0 <= ilimit && zsa_ring32(R, ip0 - 2) == RD32(ip0 - rep2)) {
                 u32 const rLength = zsa_count_wave(R, ip0 + 4 - 2, ip0 + 4 - rep2 - 2, iend - 2, lane) + 4;
                 { u32 const t = rep2; rep2 = rep1; rep1 = t; }
@@ -315,207 +302,19 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, const TAB T, u32* ringWords, u
                     wv_lds_fence();
                 }
                 ip0 += rLength;
-                if (lane == 0) seqStage[nbSeq & 63] = zsa_packseq(0, rLength - ZSA_MINMATCH, 1);
+                if (lane == 0) seqOut[nbSeq] = zsa_packseq(0, rLength - ZSA_MINMATCH, 1);
                 nbSeq++;
-                if ((nbSeq & 63) == 0) { wv_lds_fence(); seqOut[nbSeq - 64 + (u32)lane] = seqStage[lane]; wv_lds_fence(); }
                 anchor = ip0;
                 if (R.hi < ip0 - 2 + 512 && R.hi < R.limit) zsa_ring_fill(R, ip0 - 2 + 1024, lane);
             }
+            blockDone = true;
             break;
         }
-        bool blockDone = false;
         for (;;) {   // one window per iteration
-            // the parse state is the same in every lane: keep it in scalar registers (see wv_uniform): the chunk path's event
-            // pick is scalar bit arithmetic on ballots
-            if (TAB::filtered) {
-                ip0 = wv_uniform(ip0); anchor = wv_uniform(anchor); rep1 = wv_uniform(rep1); rep2 = wv_uniform(rep2);
-                nbSeq = wv_uniform(nbSeq); step = wv_uniform(step); sNext = wv_uniform(sNext); nextStep = wv_uniform(nextStep);
-                chkRep2 = wv_uniform_b(chkRep2); havePre = wv_uniform_b(havePre);
-                R.lo = wv_uniform(R.lo); R.hi = wv_uniform(R.hi);
-                winB = wv_uniform(winB); winValid = wv_uniform(winValid); winH = wv_uniform64(winH); ins = wv_uniform64(ins);
-                mOffA = wv_uniform(mOffA); mOffB = wv_uniform(mOffB); mA = wv_uniform64(mA); mB = wv_uniform64(mB);
-            }
             {   u32 const want = ip0 - 2 + 1024;
                 if (R.hi < want && R.hi < R.limit) zsa_ring_fill(R, want, lane);
             }
 
-            // ---- chunk path.  While the step is 2 every position from ip0 on is visited, so the per-position work that does
-            // not depend on the parse state -- source word, hash, fingerprint, probe -- is done once for 64 consecutive
-            // positions (lane k <-> position winB + k) and reused by every search that starts inside the chunk.  The probe
-            // reads the LDS filter only; a lane whose filter nibble equals its fingerprint's MAY match.  What remains per
-            // sequence: a repcode compare (one mask per offset, cached), a scalar pick of the first event in the reference's
-            // order, ONE global cell read by the winning lane (position + full fingerprint), the match extension.  Positions
-            // that enter the table are collected in `ins` and written when the chunk is left (commit).
-            // Exactness: the probe of lane b is what the serial walk sees as long as no earlier lane of the chunk falls into
-            // the same cell (inserts happen in position order, so only earlier lanes can have written it since set-up).
-            // Set-up finds all lanes that share a cell with another one (a bitmap pass over the cell numbers); lanes below
-            // the second-lowest of them -- winValid -- are safe, and the chunk is set up again when the parse gets there.
-            if (TAB::filtered && useFp && stepSize == 2 && step == 2 && sNext == 2) {
-                u32 const iE = (ilimit - ip0 - 2) >> 1;                      // pairs the reference still enters (`ip3 < ilimit`, :328)
-                u32 const room = nextStep - ip0;
-                u32 const nStp = room > 4 ? (room - 3) >> 1 : 0;             // pairs before the step grows (:322-327)
-                u32 const nES = iE < nStp ? iE : nStp;
-                // pairs (ip0 + 2i, ip0 + 2i + 1) the chunk covers: both lanes below winValid, the repcode lane ip0 + 2i + 2 <= 63
-                auto cover = [&](u32 o) -> u32 {
-                    if (o > 61 || o >= winValid) return 0;
-                    u32 const a = (63u - o) >> 1, b = (winValid - o) >> 1;
-                    return a < b ? a : b;
-                };
-                u32 o = ip0 - winB, n = 0;
-                if (nES) {
-                    if (winValid) n = cover(o);
-                    if (n == 0 && !(winValid && o == 0)) {
-                        commit();
-                        ZSA_STAT(0);
-                        winB = ip0; o = 0;
-                        u32 const q = winB + (u32)lane;
-                        wv64 = zsa_ring64(R, q - 2);
-                        whash = zsa_hashT<MLS>(wv64, hlog);
-                        wcell = (ZSA_FPV(wv64) << posBits) | q;
-                        wnib = T.fget(whash);
-                        winH = wv_ballot(wnib == (wcell >> 28));
-                        // lanes that share their cell with another lane: the first lane to reach a cell's bit finds it clear, the
-                        // others find it set and clear it again, which tells the first one
-                        u32* const dw = T.dupWord(whash);
-                        u32 const bit = 1u << (whash & 31u);
-                        bool const late = (wv_atomic_or_lds(dw, bit) & bit) != 0;
-                        wv_lds_fence();
-                        if (late) (void)wv_atomic_and_lds(dw, ~bit);
-                        wv_lds_fence();
-                        bool const shares = late || !(*dw & bit);
-                        wv_lds_fence();
-                        *dw = 0;
-                        wv_lds_fence();
-                        u64 const G = wv_ballot(shares);
-                        u64 const G2 = G & (G - 1);
-                        winValid = G2 ? (u32)__builtin_ctzll(G2) : 64u;
-                        if (winValid == 0) winValid = 1;   // (cannot happen: the second-lowest lane is at least 1)
-                        mOffA = mOffB = 0;
-                        n = cover(0);
-                    }
-                    if (n > nES) n = nES;
-                }
-                if (n) {
-                    auto repMask = [&](u32 off) -> u64 {   // lanes whose 4 bytes equal the 4 bytes `off` before them
-                        if (off == mOffA) return mA;
-                        if (off == mOffB) return mB;
-                        u32 const q = winB + (u32)lane;
-                        u32 const a = q - 2 - off;
-                        u32 rv = zsa_ring32(R, a);                               // masked ring address, always legal
-                        if (ip0 - 2 - off < R.lo) {                              // uniform: older than the ring
-                            rv = ~(u32)wv64;
-                            if ((u32)lane >= o && q + 4 <= iend) rv = wv_ldg32_now(R.src + a);
-                        }
-                        u64 const m = wv_ballot(rv == (u32)wv64);
-                        mOffB = mOffA; mB = mA; mOffA = off; mA = m;
-                        return m;
-                    };
-                    if (chkRep2 && ((repMask(rep2) >> o) & 1)) {   // immediate repcode (zstd_fast.c:311-324)
-                        u32 fwd, bwd;
-                        zsa_extend16(R, ip0 + 4 - 2, ip0 + 4 - rep2 - 2, iend - 2, ip0 - 2, ip0 - rep2 - 2, 0, &fwd, &bwd, lane);
-                        u32 const rLength = fwd + 4;
-                        { u32 const t = rep2; rep2 = rep1; rep1 = t; }
-                        ZSA_STAT(1);
-                        ins |= 1ull << o;
-                        ip0 += rLength;
-                        if (lane == 0) seqStage[nbSeq & 63] = zsa_packseq(0, rLength - ZSA_MINMATCH, 1);
-                        nbSeq++;
-                        if ((nbSeq & 63) == 0) { wv_lds_fence(); seqOut[nbSeq - 64 + (u32)lane] = seqStage[lane]; wv_lds_fence(); }
-                        anchor = ip0;
-                        chkRep2 = (ip0 <= ilimit) && rep2 > 0;
-                        havePre = false;
-                        if (R.hi < ip0 - 2 + 512 && R.hi < R.limit) zsa_ring_fill(R, ip0 - 2 + 1024, lane);
-                        break;   // back to _start with the new ip0
-                    }
-                    u64 const R1 = rep1 ? repMask(rep1) : 0;
-                    u64 const lowH = (1ull << (2 * n)) - 1;                  // n <= 31
-                    u64 Hs = (winH >> o) & lowH;
-                    u64 const Rs = (R1 >> o) & 0x5555555555555554ull & ((lowH << 1) | 1);
-                    ZSA_PPROF(S, lane, 8);
-                    int evRel = -1; u32 evRole = 0, evCand = 0, vFwd = 0, vBwd = 0;
-                    for (;;) {
-                        // order of events: the repcode check at ip0 + 2i + 2 precedes the two table checks of pair i
-                        u32 const fh = Hs ? (u32)__builtin_ctzll(Hs) : 64u, fr = Rs ? (u32)__builtin_ctzll(Rs) : 64u;
-                        if (fh == 64 && fr == 64) break;
-                        if (fr != 64 && fr <= fh + 2) { evRel = (int)fr; evRole = 0; break; }
-                        // the winning lane reads its cell: position, and the fingerprint bits the filter does not hold
-                        u32 const L = o + fh, cur = ip0 + fh;
-                        u32 x = 0;
-                        if ((u32)lane == L) x = T.ld(whash) ^ wcell;
-                        x = wv_readlane(x, (int)L);
-                        u32 const m = (x & posMask) ^ cur;
-                        if ((x >> posBits) == 0 && m >= prefixStartIndex) {
-                            u32 const mb = (cur - anchor) < (m - prefixStartIndex) ? (cur - anchor) : (m - prefixStartIndex);
-                            zsa_extend16(R, cur - 2, m - 2, iend - 2, cur - 2, m - 2, mb, &vFwd, &vBwd, lane);
-                            if (vFwd >= 4) { evRel = (int)fh; evRole = 1 + (fh & 1); evCand = m; break; }
-                        }
-                        ZSA_STAT(6);
-                        winH &= ~(1ull << L); Hs &= ~(1ull << fh);           // the filter let it through, the bytes differ: not an event
-                    }
-                    chkRep2 = false; havePre = false;
-                    ZSA_STAT(evRel < 0 ? 2 : 3);
-                    if (evRel < 0) {   // no event: all n pairs enter the table
-                        ins |= lowH << o;
-                        if (n == iE) { blockDone = true; break; }
-                        ip0 += 2 * n;
-                        continue;
-                    }
-                    // positions that enter the table (:266, :278, :300-303): up to the event's pair, plus the next pair's first
-                    // position when the second check hit (step <= 4)
-                    u32 const i2 = evRole == 0 ? (u32)evRel - 2 : ((u32)evRel & ~1u);
-                    u32 const cnt = evRole == 2 ? i2 + 3 : i2 + 2;
-                    ins |= ((1ull << cnt) - 1) << o;
-                    ZSA_PPROF(S, lane, 9);
-                    u32 current0, match0, mLength, offcode;
-                    if (evRole == 0) {
-                        current0 = ip0 + i2;
-                        ip0 = current0 + 2;
-                        match0 = ip0 - rep1;
-                        offcode = 1;
-                        u32 fwd, bwd;
-                        zsa_extend16(R, ip0 + 4 - 2, match0 + 4 - 2, iend - 2, ip0 - 2, match0 - 2, 1, &fwd, &bwd, lane);
-                        ip0 -= bwd; match0 -= bwd;
-                        mLength = 4 + bwd + fwd;
-                    } else {
-                        current0 = ip0 + (u32)evRel;
-                        ip0 = current0;
-                        match0 = evCand;
-                        rep2 = rep1;
-                        rep1 = ip0 - match0;
-                        offcode = rep1 + 3;
-                        ip0 -= vBwd; match0 -= vBwd;
-                        mLength = vBwd + vFwd;
-                    }
-                    if (lane == 0) seqStage[nbSeq & 63] = zsa_packseq(ip0 - anchor, mLength - ZSA_MINMATCH, offcode);
-                    nbSeq++;
-                    if ((nbSeq & 63) == 0) { wv_lds_fence(); seqOut[nbSeq - 64 + (u32)lane] = seqStage[lane]; wv_lds_fence(); }
-                    ip0 += mLength;
-                    anchor = ip0;
-                    if (ip0 <= ilimit) {
-                        if (R.hi < ip0 - 2 + 512 && R.hi < R.limit) zsa_ring_fill(R, ip0 - 2 + 1024, lane);
-                        u32 const pA = current0 + 2, pB = ip0 - 2;   // :307-309, in this order
-                        u32 const lA = pA - winB, lB = pB - winB;
-                        if (lB < 64) ins |= (1ull << lA) | (1ull << lB);
-                        else {   // the match left the chunk: write what is pending, then these two
-                            if (lA < 64) ins |= 1ull << lA;
-                            commit();
-                            u32 const pp = lane == 0 ? pA : pB;
-                            u32 hh = 0; u64 wd = 0;
-                            if (lane < 2) { wd = RD64(pp); hh = zsa_hashT<MLS>(wd, hlog); }
-                            if (lane == 0 && lA >= 64) T.st(hh, ZSA_CELL(pp, wd));
-                            wv_lds_fence();
-                            if (lane == 1) T.st(hh, ZSA_CELL(pp, wd));
-                            wv_lds_fence();
-                            winValid = 0;
-                        }
-                        chkRep2 = rep2 > 0;
-                    }
-                    ZSA_PPROF(S, lane, 10);
-                    break;   // goto _start
-                }
-                ZSA_STAT(nES ? 4 : 5);
-            }
-            if (TAB::filtered) { commit(); winValid = 0; }   // the general evaluation below reads and writes the table itself
             // ---- positions of this window: P_0 = ip0, P_{i+1} = P_i + s_i, s_{i+1} = step at that time (zstd_fast.c:316-327).
             // pos = the position this lane looks at: P_pair (+1) for the hash lanes, P_{pair+1} for the repcode lane.
             bool const fast = (step == 2) & (sNext == 2) & (ip0 + 2 + ZSA_NP * 2 < nextStep);
@@ -581,7 +380,6 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, const TAB T, u32* ringWords, u
                 }
             }
             u64 const found = wv_ballot(ok);
-            ZSA_PPROF(S, lane, 8);
             u32 const nv = (u32)__builtin_popcountll(vm) >> 1;
             if (found >> 63) {   // immediate repcode: nothing of the speculative window happened
                 u32 const rLength = zsa_count_wave(R, ip0 + 4 - 2, ip0 + 4 - rep2 - 2, iend - 2, lane) + 4;
@@ -592,17 +390,15 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, const TAB T, u32* ringWords, u
                     wv_lds_fence();
                 }
                 ip0 += rLength;
-                if (lane == 0) seqStage[nbSeq & 63] = zsa_packseq(0, rLength - ZSA_MINMATCH, 1);
+                if (lane == 0) seqOut[nbSeq] = zsa_packseq(0, rLength - ZSA_MINMATCH, 1);
                 nbSeq++;
-                if ((nbSeq & 63) == 0) { wv_lds_fence(); seqOut[nbSeq - 64 + (u32)lane] = seqStage[lane]; wv_lds_fence(); }
                 anchor = ip0;
                 chkRep2 = (ip0 <= ilimit) && rep2 > 0;
                 if (stepSize == 2 && ip0 + 3 < ilimit) {
                     if (R.hi < ip0 - 2 + 512 && R.hi < R.limit) zsa_ring_fill(R, ip0 - 2 + 1024, lane);
                     vPre = zsa_ring64(R, ((chkRep2 && lane == 63) ? ip0 : ip0 + fastOff) - 2); havePre = true;
                 }
-                ZSA_PPROF(S, lane, 10);
-                break;   // back to _start with the new ip0
+                    break;   // back to _start with the new ip0
             }
             chkRep2 = false;
 
@@ -660,7 +456,6 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, const TAB T, u32* ringWords, u
             wv_lds_fence();
             if (extra && !xInWin) { u64 const vx = RD64(xP); u32 const hx = zsa_hashT<MLS>(vx, hlog); if (lane == 0) T.st(hx, ZSA_CELL(xP, vx)); wv_lds_fence(); }
 
-            ZSA_PPROF(S, lane, 9);
             u32 current0, match0, mLength, offcode, maxBack;
             if (wRole == 0) {
                 current0 = wP;
@@ -686,12 +481,10 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, const TAB T, u32* ringWords, u
                 ip0 -= bwd; match0 -= bwd;
                 mLength = 4 + bwd + fwd;
             }
-            if (lane == 0) seqStage[nbSeq & 63] = zsa_packseq(ip0 - anchor, mLength - ZSA_MINMATCH, offcode);
+            if (lane == 0) seqOut[nbSeq] = zsa_packseq(ip0 - anchor, mLength - ZSA_MINMATCH, offcode);
             nbSeq++;
-            if ((nbSeq & 63) == 0) { wv_lds_fence(); seqOut[nbSeq - 64 + (u32)lane] = seqStage[lane]; wv_lds_fence(); }
             ip0 += mLength;
             anchor = ip0;
-            ZSA_PPROF(S, lane, 10);
             if (ip0 <= ilimit) {
                 if (R.hi < ip0 - 2 + 512 && R.hi < R.limit) zsa_ring_fill(R, ip0 - 2 + 1024, lane);
                 if (stepSize == 2 && ip0 + 3 < ilimit) {   // first window of the next search: step 2, positions ip0 + fastOff
@@ -714,47 +507,324 @@ ZSA_DEV u32 zsa_parse_fast_waveT(ZsaEncShared* S, const TAB T, u32* ringWords, u
         }
         if (blockDone) break;
     }
+    st.ip0 = ip0; st.anchor = anchor; st.rep1 = rep1; st.rep2 = rep2; st.nbSeq = nbSeq; st.chkRep2 = chkRep2 ? 1u : 0u;
+    st.midEpisode = 0; st.nextStep = 0; st.rlo = R.lo; st.rhi = R.hi; st.done = blockDone ? 1u : 0u;
+}
+
+// the same, compiled once per (minMatch, table kind) as a function of its own: the chunk path below then owns its registers
+template <int MLS, class TAB>
+ZSA_DEVFN void zsa_parse_general(const TAB T, u32* ringWords, u8* tags, const ZsaParseCtx* C, ZsaParseState* st, u32 until)
+{
+    zsa_parse_general_body<MLS, TAB>(T, ringWords, tags, *C, *st, until, wv_lane());
+}
+
+// continuation of a match that ran past the first round of zsa_chunk_extend (rare: kept out of line)
+ZSA_DEVFN u32 zsa_count_far(const u8* ringB, const u8* src, u32 lo, u32 hi, u32 limit, u32 ip, u32 m, u32 iend)
+{
+    ZsaRing R; R.b = (u8*)ringB; R.src = src; R.lo = lo; R.hi = hi; R.limit = limit;
+    return zsa_count_wave(R, ip, m, iend, wv_lane());
+}
+ZSA_DEVFN u32 zsa_back_far(const u8* ringB, const u8* src, u32 lo, u32 hi, u32 limit, u32 ipB, u32 mB, u32 maxBack)
+{   // zstd_fast.c:285-289 beyond the first 16 bytes, 64 bytes per step
+    ZsaRing R; R.b = (u8*)ringB; R.src = src; R.lo = lo; R.hi = hi; R.limit = limit;
+    int const lane = wv_lane();
+    u32 nb = 16;
+    while (nb < maxBack) {
+        u32 const kk = nb + (u32)lane;
+        bool const e = (kk < maxBack) && (zsa_rd8(R, ipB - 1 - kk) == zsa_rd8(R, mB - 1 - kk));
+        u64 const ne = wv_ballot(!e);
+        u32 const f = ne ? (u32)__builtin_ctzll(ne) : 64u;
+        nb += f;
+        if (f < 64) break;
+    }
+    return nb;
+}
+
+// ---- CHUNK PATH (levels 1 and 2 without a dictionary; ZsaTabFilt).  While the step is 2 every position from ip0 on is
+// visited, so the per-position work that does not depend on the parse state -- source word, hash, fingerprint, probe -- is
+// done once for 64 consecutive positions (lane k <-> position winB + k) and reused by every search that starts inside the
+// chunk.  The probe reads the LDS filter only; a lane whose filter nibble equals its fingerprint's MAY match.  What remains
+// per sequence: a repcode compare (one mask per offset, kept while the offset lives), a scalar pick of the first event in the
+// reference's order, ONE global cell read by the winning lane (position + the full fingerprint), the match extension.
+// Positions that enter the table are collected in `ins` and written when the chunk is left (commit).
+// Exactness: the probe of lane b is what the serial walk sees as long as no earlier lane of the chunk falls into the same
+// cell (inserts happen in position order, so only earlier lanes can have written it since set-up).  Set-up finds all lanes
+// that share a cell with another one (a bitmap pass over the cell numbers); lanes below the second-lowest of them --
+// winValid -- are safe, and the chunk is set up again when the parse gets there.
+// Everything the chunk path does not do itself -- the step growing after 128 bytes without a match, the last 288 bytes of a
+// block -- is handed back to the caller, which runs the general evaluation up to the next search restart.
+// ring fill out of line (about once per KiB of input): returns the new R.hi
+ZSA_DEVFN u32 zsa_ring_fill_far(u8* ringB, const u8* src, u32 hi, u32 want, u32 limit)
+{
+    ZsaRing R; R.b = ringB; R.src = src; R.lo = 0; R.hi = hi; R.limit = limit;
+    if (want > hi + 2 * ZSA_RING_BYTES) R.hi = (want - ZSA_RING_BYTES) & ~1023u;   // a long match: nothing of what it skipped is read again through the ring
+    zsa_ring_fill(R, want, wv_lane());
+    return R.hi;
+}
+// (written with integer flags and one flat loop on purpose: the loop-carried state then stays in scalar registers and every
+// branch is a scalar compare; booleans carried around a loop turn into 64-bit lane masks)
+template <int MLS>
+ZSA_DEVFN void zsa_parse_chunk(const ZsaTabFilt T, u32* ringWords, const ZsaParseCtx* Cp, ZsaParseState* stp, u32* backoff)
+{
+    int const lane = wv_lane();
+    ZsaParseCtx const& C = *Cp; ZsaParseState& st = *stp;
+    u32 const hlog = wv_uniform(C.hlog), posBits = wv_uniform(C.posBits), iend = wv_uniform(C.iend), ilimit = iend - 8;
+    u32 const prefixStartIndex = wv_uniform(C.prefixStartIndex);
+    u64* const seqOut = (u64*)wv_uniform64((u64)C.seqOut);
+    bool const useFp = true;
+    u32 const posMask = (1u << posBits) - 1u;
+    u32 const safeEnd = iend > 288 ? iend - 288 : 0;            // chunks start at or below it: every lane's 8 bytes, all pairs and the
+                                                                // first extension round then lie inside the block
+    ZsaRing R;
+    R.b = (u8*)ringWords; R.src = (const u8*)wv_uniform64((u64)C.base) + 2; R.limit = iend - 2; R.lo = wv_uniform(st.rlo); R.hi = wv_uniform(st.rhi);
+    u32 ip0 = wv_uniform(st.ip0), anchor = wv_uniform(st.anchor), rep1 = wv_uniform(st.rep1), rep2 = wv_uniform(st.rep2), nbSeq = wv_uniform(st.nbSeq);
+    u32 chk = wv_uniform(st.chkRep2), mid = wv_uniform(st.midEpisode);
+    u32 nextStep = mid ? wv_uniform(st.nextStep) : ip0 + 128;
+    u32 winB = 0, winValid = 0, winEnd = 0;                 // chunk base; lanes [0, winValid) have exact probes (0: no chunk); winEnd = winB + min(63, winValid)
+    u32 ipStop = 0;                                         // beyond it no pair can be decided here: min(winB + min(61, winValid - 2), nextStep - 7)
+    u64 winH = 0;                                           // lanes whose probe passes the filter
+    u64 wv64 = 0; u32 whash = 0, wcell = 0, wnib = 0;       // per lane: source word, cell number, own cell value, filter nibble at set-up
+    u32 insV = 0;                                           // per lane: the position entered the table since set-up (not yet written)
+    u32 lateA = 0, lateB = 0;                               // positions beyond the chunk that enter the table after what is pending
+    u32* const tabP = T.p;
+    u64 M1 = 0, M2 = 0; u32 M1off = 0, M2off = 0;
+#define ZSA_REPMASK(off, OUT) do { \
+        u32 const a_ = winB + (u32)lane - 2 - (off); \
+        u32 rv_ = zsa_ring32(R, a_);                                 /* masked ring address, always legal */ \
+        if (ip0 - 2 - (off) < R.lo) {                                /* uniform: older than the ring (in the block: chunks start at or below safeEnd) */ \
+            rv_ = ~(u32)wv64; \
+            if ((u32)lane >= o) rv_ = wv_ldg32_now(R.src + a_); \
+        } \
+        OUT = wv_ballot(rv_ == (u32)wv64); } while (0)
+    for (;;) {
+        if (ip0 > ipStop) {   // the step is about to grow (:322-327), or no pair of the chunk at hand can be decided
+            // write the positions that entered the table since the chunk was set up.  Lanes below winValid fall into
+            // distinct cells that nothing else has written since; the few beyond it follow one by one, in position order
+            // (== time order), then the (at most two) positions beyond the chunk
+            if (winValid) {
+                bool const mine = insV != 0;
+                if (mine && (u32)lane < winValid) { wv_stg_cell(tabP + whash, wcell); u32 const d = wnib ^ (wcell >> 28); if (d) T.fxor(whash, d); }
+                for (u64 t = wv_ballot(mine && (u32)lane >= winValid); t; t &= t - 1) {
+                    wv_lds_fence();
+                    ZSA_STAT(7);
+                    if (lane == __builtin_ctzll(t)) { wv_stg_cell(tabP + whash, wcell); u32 const d = T.fget(whash) ^ (wcell >> 28); if (d) T.fxor(whash, d); }
+                }
+                wv_lds_fence();
+                insV = 0;
+            }
+            winValid = 0; ipStop = 0;
+            if (lateB) {
+                if (R.hi < lateB + 16 && R.hi < R.limit) { R.hi = wv_uniform(zsa_ring_fill_far(R.b, R.src, R.hi, lateB + 1024, R.limit)); if (R.hi - R.lo > ZSA_RING_BYTES) R.lo = R.hi - ZSA_RING_BYTES; }
+                u32 const pp = lane == 0 ? lateA : lateB;
+                u32 hh = 0, cell = 0;
+                if (lane < 2) { u64 const wd = zsa_ring64(R, pp - 2); hh = zsa_hashT<MLS>(wd, hlog); cell = ZSA_CELL(pp, wd); }
+                if (lane == 0 && lateA) { wv_stg_cell(tabP + hh, cell); u32 const d = T.fget(hh) ^ (cell >> 28); if (d) T.fxor(hh, d); }
+                wv_lds_fence();
+                if (lane == 1) { wv_stg_cell(tabP + hh, cell); u32 const d = T.fget(hh) ^ (cell >> 28); if (d) T.fxor(hh, d); }
+                wv_lds_fence();
+                lateA = lateB = 0;
+            }
+            if (nextStep - ip0 <= 6 || ip0 > safeEnd) break;
+            {   u32 const want = ip0 - 2 + 1024;
+                if (R.hi < want && R.hi < R.limit) { R.hi = wv_uniform(zsa_ring_fill_far(R.b, R.src, R.hi, want, R.limit)); if (R.hi - R.lo > ZSA_RING_BYTES) R.lo = R.hi - ZSA_RING_BYTES; }
+            }
+            ZSA_STAT(0);
+            winB = ip0;
+            u32 const q = winB + (u32)lane;
+            wv64 = zsa_ring64(R, q - 2);
+            whash = zsa_hashT<MLS>(wv64, hlog);
+            wcell = (ZSA_FPV(wv64) << posBits) | q;
+            wnib = T.fget(whash);
+            winH = wv_ballot(wnib == (wcell >> 28));
+            // lanes that share their cell with another lane: the first lane to reach a cell's bit finds it clear, the
+            // others find it set and clear it again, which tells the first one
+            u32* const dw = T.dupWord(whash);
+            u32 const bit = 1u << (whash & 31u);
+            bool const late = (wv_atomic_or_lds(dw, bit) & bit) != 0;
+            wv_lds_fence();
+            if (late) (void)wv_atomic_and_lds(dw, ~bit);
+            wv_lds_fence();
+            bool const shares = late || !(*dw & bit);
+            wv_lds_fence();
+            *dw = 0;
+            wv_lds_fence();
+            u64 const G = wv_ballot(shares);
+            u64 const G2 = G & (G - 1);
+            winValid = G2 ? (u32)__builtin_ctzll(G2) : 64u;
+            M1off = M2off = 0;
+            if (winValid < 2) { *backoff = ip0 + 96; winValid = 0; ZSA_STAT(4); break; }   // (lanes 0 and 1 share a cell: runs of equal bytes)
+            winEnd = winB + (winValid < 63 ? winValid : 63u);
+            {   u32 const a = winEnd - 2, b = nextStep - 7;   // (winB + min(61, winValid - 2))
+                ipStop = a < b ? a : b;
+            }
+        }
+        u32 const o = ip0 - winB;
+        u32 lim;   // twice the number of pairs decided here, >= 2: both lanes of a pair below winValid, the repcode lane ip0 + 2i + 2 <= 63,
+        {          // no step increase before them
+            u32 const a = nextStep - 3;
+            lim = ((winEnd < a ? winEnd : a) - ip0) & ~1u;
+        }
+        // repcode compares of the chunk's lanes against the two offsets (4 bytes each, lanes >= o matter): kept while the
+        // offset they were made for lives (M1off / M2off; 0: none)
+        if (chk && M2off != rep2) { ZSA_REPMASK(rep2, M2); M2off = rep2; }
+        if (rep1 && M1off != rep1) { ZSA_REPMASK(rep1, M1); M1off = rep1; }
+        // candidates in the reference's order: the immediate repcode at ip0 (zstd_fast.c:311-324), then per pair the
+        // repcode check at ip0 + 2i + 2 and the two table checks.  One of three kinds of event is taken; what follows is
+        // written with selects rather than branches (see the note above the function).
+        u32 const isR2 = chk & (u32)(M2 >> o) & 1u;
+        chk = 0;
+        u32 fh, fr = 64;
+        {   u64 const Hs = winH >> o;
+            fh = Hs ? (u32)__builtin_ctzll(Hs) : 64u;
+            if (fh >= lim) fh = 64;
+            u64 const Rs = (M1 >> o) & 0x5555555555555554ull;
+            fr = Rs ? (u32)__builtin_ctzll(Rs) : 64u;
+            if (fr > lim || rep1 == 0) fr = 64;
+        }
+        u32 const isRep = (isR2 == 0 && fr != 64 && fr <= fh + 2) ? 1u : 0u;
+        u32 const isHash = (isR2 == 0 && isRep == 0 && fh != 64) ? 1u : 0u;
+        if ((isR2 | isRep | isHash) == 0) {   // no event: all pairs enter the table, the search goes on
+            ZSA_STAT(2);
+            insV |= ((u32)lane - o < lim) ? 1u : 0u;
+            ip0 += lim;
+            mid = 1;
+            continue;
+        }
+        u32 const cur = ip0 + (isRep ? fr : (isHash ? fh : 0u));         // where the event is
+        // a table event: the winning lane reads its cell -- position, and the fingerprint bits the filter does not hold
+        u32 const L = (o + fh) & 63u;
+        u32 x = 0;
+        if ((u32)lane == L && isHash) x = wv_ldg_cell(tabP + whash) ^ wcell;
+        x = wv_readlane(x, (int)L);
+        u32 const m = isHash ? ((x & posMask) ^ cur) : cur - (isR2 ? rep2 : rep1);
+        if (isHash && ((x >> posBits) != 0 || m < prefixStartIndex)) { ZSA_STAT(6); winH &= ~(1ull << L); continue; }   // the filter let it through: not an event
+        // one round of match extension: lanes 0..15 compare 8 bytes each forwards from (cur + four, m + four), lanes
+        // 48..63 one byte each backwards from (cur - 1, m - 1) for at most eBack bytes (the source side lies in the ring;
+        // a candidate older than the ring costs one or two lines).  A repcode's 4 bytes are known to match (:259-265).
+        u32 const four = isHash ? 0u : 4u;
+        u32 eBack;
+        {   u32 const ba = cur - anchor, bb = m - prefixStartIndex;
+            eBack = isHash ? (ba < bb ? ba : bb) : isRep;
+        }
+        u32 fwd, bwd;
+        {   bool const fw = lane < 16;
+            u32 const k = (u32)lane - 48u;
+            u32 const dl = fw ? four + 8u * (u32)lane : 0u - 1u - k;
+            u32 const a = cur + dl - 2, b = m + dl - 2;                  // frame offsets
+            u64 const sa = zsa_ring64(R, a);                             // masked ring address: legal in every lane
+            u64 sb;
+            if (m - 2 >= R.lo + 16) sb = zsa_ring64(R, b);               // uniform: the candidate lies in the ring as well
+            else { sb = ~sa; if (fw || (lane >= 48 && k < eBack)) sb = wv_ldg64_now(R.src + b); }
+            u64 const diff = sa ^ sb;
+            u32 const eq = diff ? ((u32)__builtin_ctzll(diff) >> 3) : 8;
+            bool const stop = fw ? eq < 8 : !((k < eBack) && eq > 0);
+            u64 const sbal = wv_ballot(stop);
+            u32 const sf = (u32)sbal & 0xFFFFu, sk = (u32)(sbal >> 48);
+            if (sf) { int const f = __builtin_ctz(sf); fwd = 8u * (u32)f + wv_readlane(eq, f); }
+            else fwd = 128 + wv_uniform(zsa_count_far(R.b, R.src, R.lo, R.hi, R.limit, cur + four - 2 + 128, m + four - 2 + 128, iend - 2));   // (a call's result counts as per-lane)
+            if (sk) bwd = (u32)__builtin_ctz(sk);
+            else bwd = wv_uniform(zsa_back_far(R.b, R.src, R.lo, R.hi, R.limit, cur - 2, m - 2, eBack));
+        }
+        if (isHash && fwd < 4) { ZSA_STAT(6); winH &= ~(1ull << L); continue; }   // the fingerprint let it through, the bytes differ: not an event
+        ZSA_STAT(isR2 ? 1 : 3);
+        u32 const start = cur - bwd, mLength = four + bwd + fwd;
+        {   // (packed by the lanes: the vector unit has the spare issue slots here)
+            u32 const vz = (u32)lane & 0u;
+            u64 const sq = zsa_packseq((start - anchor) | vz, (mLength - ZSA_MINMATCH) | vz, (isHash ? (cur - m) + 3u : 1u) | vz);   // (an immediate repcode starts at the anchor)
+            if (lane == 0) wv_stg64(seqOut + nbSeq, sq);
+        }
+        nbSeq++;
+        ip0 = start + mLength;
+        // positions that enter the table (:266, :278, :300-303): up to the event's pair, plus the next pair's first position
+        // when the second table check hit (step <= 4); an immediate repcode enters its own position (:318).  Then
+        // (:307-309) current0 + 2 and ip0 - 2, in this order.
+        {   u32 const cnt = isR2 ? 1u : (isRep ? fr : (fh & ~1u) + 2u + (fh & 1u));
+            u32 const ok = (ip0 <= ilimit && isR2 == 0) ? 1u : 0u;
+            u32 const pA = cur + (isRep ? 0u : 2u), pB = ip0 - 2;
+            u32 const lA = ok ? pA - winB : 64u, lB = ok ? pB - winB : 64u;
+            insV |= (((u32)lane - o < cnt) || (u32)lane == lA || (u32)lane == lB) ? 1u : 0u;
+            if (ok && lB >= 64) { lateB = pB; if (lA >= 64) lateA = pA; }
+        }
+        // offsets (and the masks made for them): a table event pushes a new one, an immediate repcode swaps the two
+        {   u32 const shift = isHash | isR2;
+            u32 const n1 = isHash ? cur - m : (isR2 ? rep2 : rep1), n2 = shift ? rep1 : rep2;
+            u64 const nM1 = isR2 ? M2 : M1, nM2 = shift ? M1 : M2;
+            u32 const nO1 = isR2 ? M2off : M1off, nO2 = shift ? M1off : M2off;
+            rep1 = n1; rep2 = n2; M1 = nM1; M2 = nM2; M1off = nO1; M2off = nO2;
+        }
+        anchor = ip0;
+        nextStep = ip0 + 128; mid = 0;
+        {   u32 const a = winEnd - 2, b = ip0 + 121;
+            ipStop = winValid ? (a < b ? a : b) : 0u;
+        }
+        chk = (ip0 <= ilimit && rep2 != 0) ? 1u : 0u;
+    }
+#undef ZSA_REPMASK
+    st.ip0 = ip0; st.anchor = anchor; st.rep1 = rep1; st.rep2 = rep2; st.nbSeq = nbSeq; st.chkRep2 = chk;
+    st.midEpisode = mid; st.nextStep = nextStep; st.rlo = R.lo; st.rhi = R.hi; st.done = 0;
+}
 #undef RD32
 #undef RD64
 #undef RD8
-#undef ZSA_FPV
 #undef ZSA_CELL
-    commit();
-    {   u32 const n = nbSeq & 63;
-        wv_lds_fence();
-        if ((u32)lane < n) seqOut[nbSeq - n + (u32)lane] = seqStage[lane];
-        wv_lds_fence();
+
+// Parses one block.  T: the frame's match table in the workgroup's global scratch.  base: window base (index i <-> base + i, the
+// frame starts at index 2).  Returns the number of sequences appended to seqOut; rep[] and *lastLL are updated.  All values
+// are wave-uniform.  filt / dup: LDS words of the chunk path (null: general evaluation only).
+template <int MLS>
+ZSA_DEV u32 zsa_parse_fast_blockT(u32* T, u32* filt, u32* dup, u32* ringWords, u8* tags, const ZsaEncParams& P, const u8* base, u32 dictLimit,
+                                  const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL, u32 posBits, int lane)
+{
+    ZsaParseCtx C;
+    C.base = base; C.seqOut = seqOut; C.hlog = P.hlog; C.posBits = posBits;
+    C.stepSize = (P.tlen > 1) ? (P.tlen + 1) : 2;               // zstd_fast.c:153, :429
+    u32 const istart = (u32)(src - base);
+    C.iend = istart + srcSize; C.ilimit = C.iend - 8;           // indices
+    u32 const maxDistance = 1u << P.wlog;
+    // ZSTD_getLowestPrefixIndex (zstd_compress_internal.h:1307-1318), no loaded dictionary
+    C.prefixStartIndex = (C.iend - dictLimit > maxDistance) ? C.iend - maxDistance : dictLimit;
+    ZsaParseState st;
+    st.anchor = istart; st.ip0 = istart + (istart == C.prefixStartIndex);
+    st.rep1 = rep[0]; st.rep2 = rep[1]; st.nbSeq = 0; st.chkRep2 = 0; st.nextStep = 0; st.midEpisode = 0; st.done = 0;
+    st.rlo = st.rhi = (istart - 2) & ~1023u;
+    u32 saved1 = 0, saved2 = 0;
+    {   u32 const curr = st.ip0;
+        u32 const windowLow = (curr - dictLimit > maxDistance) ? curr - maxDistance : dictLimit;
+        u32 const maxRep = curr - windowLow;
+        if (st.rep2 > maxRep) { saved2 = st.rep2; st.rep2 = 0; }
+        if (st.rep1 > maxRep) { saved1 = st.rep1; st.rep1 = 0; }
+    }
+    if (filt) {
+        ZsaTabFilt tab; tab.p = T; tab.filt = filt; tab.dup = dup;
+        u32 backoff = 0;
+        for (;;) {
+            if (st.ip0 >= backoff) zsa_parse_chunk<MLS>(tab, ringWords, &C, &st, &backoff);
+            // whatever stopped the chunk path: the general evaluation takes the parse to the next search restart (or past
+            // a stretch where neighbouring positions share cells)
+            zsa_parse_general<MLS, ZsaTabFilt>(tab, ringWords, (u8*)dup, &C, &st, backoff > st.ip0 ? backoff : 0u);
+            if (wv_uniform(st.done)) break;
+        }
+    } else {
+        ZsaTabGlobal tab; tab.p = T;
+        zsa_parse_general<MLS, ZsaTabGlobal>(tab, ringWords, tags, &C, &st, 0xFFFFFFFFu);
     }
     // label _cleanup: zstd_fast.c:330-355
+    u32 const rep1 = wv_uniform(st.rep1), rep2 = wv_uniform(st.rep2);
     saved2 = ((saved1 != 0) && (rep1 != 0)) ? saved1 : saved2;
     rep[0] = rep1 ? rep1 : saved1;
     rep[1] = rep2 ? rep2 : saved2;
-    *lastLL = iend - anchor;
-    return nbSeq;
+    *lastLL = C.iend - wv_uniform(st.anchor);
+    return wv_uniform(st.nbSeq);
 }
+#undef ZSA_FPV
 
-template <class TAB>
-ZSA_DEV u32 zsa_parse_fast_wave_tab(ZsaEncShared* S, const TAB T, u32* ringWords, u64* seqStage, u8* tags, const ZsaEncParams& P, const u8* base, u32 dictLimit,
-                                    const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL, u32 posBits, int lane)
+ZSA_DEV u32 zsa_parse_fast_block(u32* T, u32* filt, u32* dup, u32* ringWords, u8* tags, const ZsaEncParams& P, const u8* base, u32 dictLimit,
+                                 const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL, u32 posBits, int lane)
 {
     switch (P.mml) {
-    case 5:  return zsa_parse_fast_waveT<5, TAB>(S, T, ringWords, seqStage, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
-    case 6:  return zsa_parse_fast_waveT<6, TAB>(S, T, ringWords, seqStage, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
-    case 7:  return zsa_parse_fast_waveT<7, TAB>(S, T, ringWords, seqStage, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
-    default: return zsa_parse_fast_waveT<4, TAB>(S, T, ringWords, seqStage, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
+    case 5:  return zsa_parse_fast_blockT<5>(T, filt, dup, ringWords, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
+    case 6:  return zsa_parse_fast_blockT<6>(T, filt, dup, ringWords, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
+    case 7:  return zsa_parse_fast_blockT<7>(T, filt, dup, ringWords, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
+    default: return zsa_parse_fast_blockT<4>(T, filt, dup, ringWords, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
     }
-}
-ZSA_DEV u32 zsa_parse_fast_wave(ZsaEncShared* S, u32* T, u32* ringWords, u64* seqStage, u8* tags, const ZsaEncParams& P, const u8* base, u32 dictLimit,
-                                const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL, u32 posBits, int lane)
-{
-    ZsaTabGlobal tab; tab.p = T;
-    return zsa_parse_fast_wave_tab<ZsaTabGlobal>(S, tab, ringWords, seqStage, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
-}
-// chunk path: `filt` = (1 << hashLog) / 8 words of LDS holding the top 4 bits of every cell, `dup` = (1 << hashLog) / 32 words, all zero
-// (it doubles as the general evaluation's tag array, which needs ZSA_NTAGS bytes)
-ZSA_DEV u32 zsa_parse_fast_wave_filt(ZsaEncShared* S, u32* T, u32* filt, u32* dup, u32* ringWords, u64* seqStage, const ZsaEncParams& P, const u8* base, u32 dictLimit,
-                                     const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL, u32 posBits, int lane)
-{
-    ZsaTabFilt tab; tab.p = T; tab.filt = filt; tab.dup = dup;
-    return zsa_parse_fast_wave_tab<ZsaTabFilt>(S, tab, ringWords, seqStage, (u8*)dup, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
 }

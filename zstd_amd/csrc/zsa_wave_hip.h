@@ -48,6 +48,7 @@ ZSA_DEV unsigned wv_vzero() { unsigned z; asm volatile("v_mov_b32 %0, 0" : "=v"(
 // aligned table cells in global memory
 ZSA_DEV unsigned wv_ldg_cell(const unsigned* p) { return *(const __attribute__((address_space(1))) unsigned*)p; }
 ZSA_DEV void wv_stg_cell(unsigned* p, unsigned v) { *(__attribute__((address_space(1))) unsigned*)p = v; }
+ZSA_DEV void wv_stg64(void* p, unsigned long long v) { *(__attribute__((address_space(1))) unsigned long long*)p = v; }
 ZSA_DEV void wv_stg8(unsigned char* p, unsigned v) { *(__attribute__((address_space(1))) unsigned char*)p = (unsigned char)v; }
 // The same loads, completed before control leaves the call.  For the rarely-taken global side of an "LDS or global"
 // read: gfx950 counts loads and stores in one counter (vmcnt), so if a pending load could reach the join of the two
