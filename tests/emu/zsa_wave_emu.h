@@ -80,6 +80,7 @@ ZSA_DEV unsigned long long wv_uniform64(unsigned long long v, int line = __built
 }
 ZSA_DEV unsigned wv_uniform(unsigned v, int line = __builtin_LINE()) { return (unsigned)wv_uniform64(v, line); }
 ZSA_DEV bool wv_uniform_b(bool v, int line = __builtin_LINE()) { return wv_uniform64(v ? 1 : 0, line) != 0; }
+ZSA_DEV unsigned wv_bfe(unsigned x, unsigned off, unsigned w) { w &= 31; return w ? (x >> (off & 31)) & ((1u << w) - 1u) : 0; }
 ZSA_DEV unsigned wv_alignbyte(unsigned hi, unsigned lo, unsigned sh) { return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (8 * (sh & 3))); }
 ZSA_DEV unsigned wv_ldg8(const unsigned char* p) { return *p; }
 ZSA_DEV unsigned wv_ldg32(const unsigned char* p) { unsigned v; memcpy(&v, p, 4); return v; }
@@ -88,6 +89,8 @@ ZSA_DEV unsigned wv_vzero() { return 0; }
 ZSA_DEV unsigned wv_ldg_cell(const unsigned* p) { return *p; }
 ZSA_DEV void wv_stg_cell(unsigned* p, unsigned v) { *p = v; }
 ZSA_DEV void wv_stg64(void* p, unsigned long long v) { *(unsigned long long*)p = v; }
+ZSA_DEV void wv_stg32(void* p, unsigned v) { memcpy(p, &v, 4); }
+ZSA_DEV void wv_stg64u(void* p, unsigned long long v) { memcpy(p, &v, 8); }
 ZSA_DEV void wv_stg8(unsigned char* p, unsigned v) { *p = (unsigned char)v; }
 ZSA_DEV unsigned wv_ldg8_now(const unsigned char* p) { return wv_ldg8(p); }
 ZSA_DEV unsigned wv_ldg32_now(const unsigned char* p) { return wv_ldg32(p); }

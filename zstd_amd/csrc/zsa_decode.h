@@ -436,6 +436,31 @@ ZSA_DEV void zsa_copy16(void* dst, const void* src, u32 bytes, int lane)
 
 ZSA_DEV void zsa_raise(ZsaDecShared* S, u32 code) { if (S->err == 0) S->err = code; }
 
+// Copies len <= 32 bytes from s to d (global memory, not overlapping), each lane its own run: up to four 8-byte moves -- at
+// 0, 8, 16 and at len - 8, which covers the end whatever len is -- or two 4-byte moves, or single bytes below 4.  All loads are
+// issued before the first store, so a lane's moves share one memory round trip.
+ZSA_DEV void zsa_copy_run32(u8* d, const u8* s, u32 len)
+{
+    if (len >= 8) {
+        u64 const a = wv_ldg64(s), t = wv_ldg64(s + len - 8);
+        u64 b = 0, c = 0;
+        if (len > 16) b = wv_ldg64(s + 8);
+        if (len > 24) c = wv_ldg64(s + 16);
+        wv_stg64u(d, a);
+        if (len > 16) wv_stg64u(d + 8, b);
+        if (len > 24) wv_stg64u(d + 16, c);
+        wv_stg64u(d + len - 8, t);
+    } else if (len >= 4) {
+        u32 const a = wv_ldg32(s), t = wv_ldg32(s + len - 4);
+        wv_stg32(d, a); wv_stg32(d + len - 4, t);
+    } else if (len) {
+        u32 const a = wv_ldg8(s), b = len > 1 ? wv_ldg8(s + 1) : 0, c = len > 2 ? wv_ldg8(s + 2) : 0;
+        wv_stg8(d, a);
+        if (len > 1) wv_stg8(d + 1, b);
+        if (len > 2) wv_stg8(d + 2, c);
+    }
+}
+
 // One compressed block.  op = output offset of the block inside the frame (relative to dstBase),
 // cap = remaining capacity.  Returns decoded size (uniform); on error S->err is set.
 ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 srcSize, u32 op, u64 cap,
@@ -633,7 +658,82 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
             // -- zstd_decompress_block.c:1185-1299 ZSTD_decodeSequence, n times on lane 0.  (Measured, round 2: the same loop run by
             // the whole wave on scalar registers -- one LDS round trip and ~70 scalar instructions per sequence -- is no faster:
             // 12 resident waves share the CU's one scalar unit, whereas lane-0 vector code spreads over four SIMDs.)
-            if (lane == 0) {
+            // Interior batches -- the 64 x 89 bits a batch can consume at most all lie above the first 8 bytes of the section,
+            // so none of the reader's end-of-buffer cases can arise -- take a reader of their own: one bit cursor into the
+            // staged bytes, the six fields of a sequence cut from one 64-bit window, and the next sequence's window requested
+            // as soon as the three cells tell how many bits this one consumes (the refill then rides on the same LDS round
+            // trip as the next cells).  The state it leaves is the one BIT_reloadDStream leaves after every sequence.
+            bool const interior = b.bitsConsumed < 8 && (size_t)(b.ptr - b.start) >= 8u + (64u * 89u + 7u) / 8u + 8u;
+            if (lane == 0 && interior) {
+                struct __attribute__((packed)) Pk { u64 v; };
+                u32 pOff = (u32)(b.ptr - stageLo), bc = b.bitsConsumed;
+                u64 W = ((const Pk*)(S->bits + pOff))->v;
+#define ZSA_TAKE(v, nb) do { v = (u32)((X >> 1) >> (63u - (nb))); X <<= (nb); } while (0)
+                for (u32 i = 0; i < n; i++) {
+                    ZsaSeqCell const ll = S->ll[stLL], ml = S->ml[stML], of = S->of[stOF];
+                    u32 const llH = (u32)(ll >> 32), mlH = (u32)(ml >> 32), ofH = (u32)(of >> 32);
+                    u32 const ofBits = (ofH >> 16) & 0xFF, mlBits = (mlH >> 16) & 0xFF, llBits = (llH >> 16) & 0xFF;
+                    u32 const llS = llH >> 24, mlS = mlH >> 24, ofS = ofH >> 24;
+                    u32 const total = ofBits + mlBits + llBits + llS + mlS + ofS;
+                    u32 ofx, mlx, llx, sl, sm, so;
+                    u32 const used = bc + total;
+#ifndef ZSA_DEC_NO32
+                    if (used <= 32) {   // the usual case: all six fields lie in the top 32 bits of the window, one bit-field extract each
+                        u32 const top = (u32)((W << bc) >> 32);
+                        u32 const o1 = ofBits, o2 = o1 + mlBits, o3 = o2 + llBits, o4 = o3 + llS, o5 = o4 + mlS;
+                        pOff -= used >> 3; bc = used & 7;
+                        W = ((const Pk*)(S->bits + pOff))->v;
+                        ofx = wv_bfe(top, 32u - o1, ofBits); mlx = wv_bfe(top, 32u - o2, mlBits); llx = wv_bfe(top, 32u - o3, llBits);
+                        sl = wv_bfe(top, 32u - o4, llS); sm = wv_bfe(top, 32u - o5, mlS); so = wv_bfe(top, 32u - total, ofS);
+                    } else
+#endif
+                    if (used <= 64) {
+                        u64 X = W << bc;
+                        pOff -= used >> 3; bc = used & 7;
+                        W = ((const Pk*)(S->bits + pOff))->v;
+                        ZSA_TAKE(ofx, ofBits); ZSA_TAKE(mlx, mlBits); ZSA_TAKE(llx, llBits);
+                        ZSA_TAKE(sl, llS); ZSA_TAKE(sm, mlS); ZSA_TAKE(so, ofS);
+                    } else {   // more than a window holds: refill after the offset and match-length bits (<= 7 + 31 + 16)
+                        u64 X = W << bc;
+                        ZSA_TAKE(ofx, ofBits); ZSA_TAKE(mlx, mlBits);
+                        {   u32 const u1 = bc + ofBits + mlBits;
+                            pOff -= u1 >> 3; bc = u1 & 7;
+                            W = ((const Pk*)(S->bits + pOff))->v; X = W << bc;
+                        }
+                        ZSA_TAKE(llx, llBits); ZSA_TAKE(sl, llS); ZSA_TAKE(sm, mlS); ZSA_TAKE(so, ofS);
+                        {   u32 const u2 = bc + llBits + llS + mlS + ofS;
+                            pOff -= u2 >> 3; bc = u2 & 7;
+                            W = ((const Pk*)(S->bits + pOff))->v;
+                        }
+                    }
+                    // offset and repeat-offset history (zstd_decompress_block.c:1236-1269).  (Branches on purpose: the common
+                    // case, a new offset, is three moves; the same logic written with selects measured 25 % slower.)
+                    u32 offset;
+                    if (ofBits > 1) {
+                        offset = (u32)of + ofx;
+                        r2 = r1; r1 = r0; r0 = offset;
+                    } else {
+                        u32 const ll0 = ((u32)ll == 0);
+                        if (ofBits == 0) {
+                            offset = ll0 ? r1 : r0;
+                            r1 = ll0 ? r0 : r1;
+                            r0 = offset;
+                        } else {
+                            u32 const code = (u32)of + ll0 + ofx;
+                            u32 temp = (code == 3) ? r0 - 1 : (code == 1 ? r1 : (code == 2 ? r2 : r0));
+                            temp += !temp;
+                            if (code != 1) r2 = r1;
+                            r1 = r0;
+                            r0 = offset = temp;
+                        }
+                    }
+                    S->seqLL[i] = (u32)ll + llx; S->seqML[i] = (u32)ml + mlx; S->seqOF[i] = offset;
+                    stLL = (llH & 0xFFFF) + sl; stML = (mlH & 0xFFFF) + sm; stOF = (ofH & 0xFFFF) + so;
+                }
+#undef ZSA_TAKE
+                b.ptr = stageLo + pOff; b.bitsConsumed = bc; b.container = W;
+                S->u[ZU_batchN] = (nbSeq == n) && (ZSA_RELOAD(b) < ZB_completed);
+            } else if (lane == 0) {
                 for (u32 i = 0; i < n; i++) {
                     ZsaSeqCell const ll = S->ll[stLL], ml = S->ml[stML], of = S->of[stOF];
                     u32 matchLength = (u32)ml, litLength = (u32)ll, offset;
@@ -698,7 +798,11 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
             wv_lds_fence();
             if (S->err) return 0;
             u32 const totalLit = wv_shfl(litIncl, 63), totalOut = wv_shfl(totIncl, 63);
-            // literals of the whole batch
+            // literals of the batch.  Runs of up to 32 bytes (nearly all of them on text-like data) are moved by the lane that owns
+            // the sequence, 8 bytes per instruction; a batch with a longer run is flattened over the lanes byte by byte.
+            if (!wv_ballot((u32)lane < n && myLL > 32)) {
+                if ((u32)lane < n) zsa_copy_run32(dst + outPos + myOutStart, litPtr + litPos + myLitStart, myLL);
+            } else
             for (u32 t = (u32)lane; t < totalLit; t += ZSA_WAVE) {
                 u32 lo = 0, hi = n - 1;
                 while (lo < hi) { u32 const mid = (lo + hi + 1) >> 1; if (S->litStart[mid] <= t) lo = mid; else hi = mid - 1; }
@@ -711,8 +815,13 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
             u32 const myO = outPos + myOutStart + myLL;
             u32 const mySpan = myOF < myML ? myOF : myML;
             bool const indep = (u32)lane < n && ((u64)myO + mySpan <= (u64)myOF + outPos);
-            u32 const mIncl = wv_scan_incl(indep ? myML : 0);
-            S->mStart[lane] = mIncl - (indep ? myML : 0);
+            // ... of which the short ones that do not overlap their own output and lie inside this frame's output are moved
+            // by the lane that owns the sequence, 8 bytes per instruction
+            bool const owned = indep && myML <= 32 && myOF >= myML && myO >= myOF;
+            if (owned) zsa_copy_run32(dst + myO, dst + myO - myOF, myML);
+            bool const flat = indep && !owned;
+            u32 const mIncl = wv_ballot(flat) ? wv_scan_incl(flat ? myML : 0) : 0;
+            S->mStart[lane] = mIncl - (flat ? myML : 0);
             u64 const depMask = wv_ballot((u32)lane < n && !indep && myML > 0);
             u32 const totalInd = wv_shfl(mIncl, 63);
             wv_lds_fence();

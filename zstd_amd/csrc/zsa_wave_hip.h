@@ -32,6 +32,8 @@ ZSA_DEV unsigned long long wv_uniform64(unsigned long long v)
 { return (unsigned long long)wv_uniform((unsigned)v) | ((unsigned long long)wv_uniform((unsigned)(v >> 32)) << 32); }
 ZSA_DEV bool wv_uniform_b(bool v) { return wv_uniform(v ? 1u : 0u) != 0; }
 // bytes [sh, sh+4) of the little-endian 8-byte value hi:lo, sh in 0..3
+// bits [off, off + w) of x (w == 0 gives 0; off is taken modulo 32)
+ZSA_DEV unsigned wv_bfe(unsigned x, unsigned off, unsigned w) { return __builtin_amdgcn_ubfe(x, off, w); }
 ZSA_DEV unsigned wv_alignbyte(unsigned hi, unsigned lo, unsigned sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
 // loads from a pointer known to be global memory (frame descriptors hand out generic pointers: without this the compiler
 // emits flat_load, which also ties up the LDS counter); unaligned addresses are fine on gfx950
@@ -49,6 +51,8 @@ ZSA_DEV unsigned wv_vzero() { unsigned z; asm volatile("v_mov_b32 %0, 0" : "=v"(
 ZSA_DEV unsigned wv_ldg_cell(const unsigned* p) { return *(const __attribute__((address_space(1))) unsigned*)p; }
 ZSA_DEV void wv_stg_cell(unsigned* p, unsigned v) { *(__attribute__((address_space(1))) unsigned*)p = v; }
 ZSA_DEV void wv_stg64(void* p, unsigned long long v) { *(__attribute__((address_space(1))) unsigned long long*)p = v; }
+ZSA_DEV void wv_stg32(void* p, unsigned v) { ((__attribute__((address_space(1))) WvPk32*)p)->v = v; }
+ZSA_DEV void wv_stg64u(void* p, unsigned long long v) { ((__attribute__((address_space(1))) WvPk64*)p)->v = v; }   // unaligned
 ZSA_DEV void wv_stg8(unsigned char* p, unsigned v) { *(__attribute__((address_space(1))) unsigned char*)p = (unsigned char)v; }
 // The same loads, completed before control leaves the call.  For the rarely-taken global side of an "LDS or global"
 // read: gfx950 counts loads and stores in one counter (vmcnt), so if a pending load could reach the join of the two
