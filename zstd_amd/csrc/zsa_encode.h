@@ -150,121 +150,6 @@ ZSA_DEV u32 zsa_count(const u8* pIn, const u8* pMatch, const u8* const pInLimit)
     return (u32)(pIn - pStart);
 }
 
-// ------------------------------------------------------------------ parse, no dictionary (zstd_fast.c:143-403), serial
-// `base` is the window base (index i <-> base + i); the frame starts at index 2.  Appends packed sequences
-// to seqOut, returns their number; *lastLL receives the size of the trailing literal run.
-ZSA_DEV u32 zsa_parse_fast(u32* hashTable, const ZsaEncParams& P, const u8* base, u32 dictLimit, u32 loadedDictEnd,
-                           const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL)
-{
-    u32 const hlog = P.hlog, mls = P.mml;
-    u32 const stepSize = (P.tlen > 1) ? (P.tlen + 1) : 2;      // zstd_fast.c:153, :429
-    const u8* const istart = src;
-    u32 const endIndex = (u32)(istart - base) + srcSize;
-    u32 const maxDistance = loadedDictEnd ? 0xFFFFFFFFu : 1u << P.wlog;
-    // ZSTD_getLowestPrefixIndex (zstd_compress_internal.h:1307-1318): with a loaded dictionary the whole prefix is valid
-    u32 const prefixStartIndex = (endIndex - dictLimit > maxDistance) ? endIndex - maxDistance : dictLimit;
-    const u8* const prefixStart = base + prefixStartIndex;
-    const u8* const iend = istart + srcSize;
-    const u8* const ilimit = iend - 8;
-    const u8* anchor = istart;
-    const u8* ip0 = istart;
-    u32 rep1 = rep[0], rep2 = rep[1], saved1 = 0, saved2 = 0;
-    u32 nbSeq = 0;
-
-    ip0 += (ip0 == prefixStart);
-    {   u32 const curr = (u32)(ip0 - base);
-        u32 const windowLow = (curr - dictLimit > maxDistance) ? curr - maxDistance : dictLimit;
-        u32 const maxRep = curr - windowLow;
-        if (rep2 > maxRep) { saved2 = rep2; rep2 = 0; }
-        if (rep1 > maxRep) { saved1 = rep1; rep1 = 0; }
-    }
-    for (;;) {
-        u32 step = stepSize;
-        const u8* nextStep = ip0 + 128;
-        const u8* ip1 = ip0 + 1;
-        const u8* ip2 = ip0 + step;
-        const u8* ip3 = ip2 + 1;
-        u32 h0, h1, idx, current0 = 0, offcode = 0, mLength = 0;
-        const u8* match0 = base;
-        int found = 0;
-        if (ip3 >= ilimit) break;
-        h0 = zsa_hash(zsa_ld64(ip0), hlog, mls);
-        h1 = zsa_hash(zsa_ld64(ip1), hlog, mls);
-        idx = hashTable[h0];
-        do {
-            u32 const rval = zsa_ld32(ip2 - rep1);
-            current0 = (u32)(ip0 - base);
-            hashTable[h0] = current0;
-            if ((zsa_ld32(ip2) == rval) & (rep1 > 0)) {
-                ip0 = ip2;
-                match0 = ip0 - rep1;
-                mLength = ip0[-1] == match0[-1];
-                ip0 -= mLength; match0 -= mLength;
-                offcode = 1;
-                mLength += 4;
-                hashTable[h1] = (u32)(ip1 - base);
-                found = 1;
-                break;
-            }
-            if (idx >= prefixStartIndex && zsa_ld32(base + idx) == zsa_ld32(ip0)) {
-                hashTable[h1] = (u32)(ip1 - base);
-                found = 2;
-                break;
-            }
-            idx = hashTable[h1];
-            h0 = h1;
-            h1 = zsa_hash(zsa_ld64(ip2), hlog, mls);
-            ip0 = ip1; ip1 = ip2; ip2 = ip3;
-            current0 = (u32)(ip0 - base);
-            hashTable[h0] = current0;
-            if (idx >= prefixStartIndex && zsa_ld32(base + idx) == zsa_ld32(ip0)) {
-                if (step <= 4) hashTable[h1] = (u32)(ip1 - base);
-                found = 2;
-                break;
-            }
-            idx = hashTable[h1];
-            h0 = h1;
-            h1 = zsa_hash(zsa_ld64(ip2), hlog, mls);
-            ip0 = ip1; ip1 = ip2;
-            ip2 = ip0 + step;
-            ip3 = ip1 + step;
-            if (ip2 >= nextStep) { step++; nextStep += 128; }
-        } while (ip3 < ilimit);
-        if (!found) break;
-        if (found == 2) {
-            match0 = base + idx;
-            rep2 = rep1;
-            rep1 = (u32)(ip0 - match0);
-            offcode = rep1 + 3;
-            mLength = 4;
-            while (((ip0 > anchor) & (match0 > prefixStart)) && (ip0[-1] == match0[-1])) { ip0--; match0--; mLength++; }
-        }
-        mLength += zsa_count(ip0 + mLength, match0 + mLength, iend);
-        seqOut[nbSeq++] = zsa_packseq((u32)(ip0 - anchor), mLength - ZSA_MINMATCH, offcode);
-        ip0 += mLength;
-        anchor = ip0;
-        if (ip0 <= ilimit) {
-            hashTable[zsa_hash(zsa_ld64(base + current0 + 2), hlog, mls)] = current0 + 2;
-            hashTable[zsa_hash(zsa_ld64(ip0 - 2), hlog, mls)] = (u32)(ip0 - 2 - base);
-            if (rep2 > 0) {
-                while ((ip0 <= ilimit) && (zsa_ld32(ip0) == zsa_ld32(ip0 - rep2))) {
-                    u32 const rLength = zsa_count(ip0 + 4, ip0 + 4 - rep2, iend) + 4;
-                    { u32 const t = rep2; rep2 = rep1; rep1 = t; }
-                    hashTable[zsa_hash(zsa_ld64(ip0), hlog, mls)] = (u32)(ip0 - base);
-                    ip0 += rLength;
-                    seqOut[nbSeq++] = zsa_packseq(0, rLength - ZSA_MINMATCH, 1);
-                    anchor = ip0;
-                }
-            }
-        }
-    }
-    saved2 = ((saved1 != 0) && (rep1 != 0)) ? saved1 : saved2;
-    rep[0] = rep1 ? rep1 : saved1;
-    rep[1] = rep2 ? rep2 : saved2;
-    *lastLL = (u32)(iend - anchor);
-    return nbSeq;
-}
-
 #include "zsa_parse.h"
 #include "zsa_dfast.h"
 #include "zsa_lazy.h"
@@ -286,123 +171,7 @@ struct ZsaWindow {
     const ZsaCDictDev* dms;   // attached dictionary, or null
 };
 
-// ------------------------------------------------------------------ parse, attached dictionary (zstd_fast.c:459-656), serial
-ZSA_DEV u32 zsa_parse_fast_dms(u32* hashTable, const ZsaEncParams& P, const ZsaWindow& Wn,
-                               const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL)
-{
-    u32 const hlog = P.hlog, mls = P.mml;
-    u32 const stepSize = P.tlen + !P.tlen;
-    const u8* const base = Wn.base;
-    const u8* const istart = src;
-    const u8* ip0 = istart;
-    const u8* ip1 = ip0 + stepSize;
-    const u8* anchor = istart;
-    u32 const prefixStartIndex = Wn.dictLimit;
-    const u8* const prefixStart = base + prefixStartIndex;
-    const u8* const iend = istart + srcSize;
-    const u8* const ilimit = iend - 8;
-    u32 offset_1 = rep[0], offset_2 = rep[1];
-    const ZsaCDictDev* const dms = Wn.dms;
-    const u32* const dictHashTable = dms->hashTable;
-    u32 const dictStartIndex = 2;
-    const u8* const dictBase = dms->content - 2;
-    const u8* const dictStart = dictBase + dictStartIndex;
-    const u8* const dictEnd = dms->content + dms->contentSize;
-    u32 const dictIndexDelta = prefixStartIndex - (u32)(dictEnd - dictBase);
-    u32 const dictAndPrefixLength = (u32)(istart - prefixStart + dictEnd - dictStart);
-    u32 const dictHBits = dms->cp.hlog + 8;
-    u32 nbSeq = 0;
-
-    ip0 += (dictAndPrefixLength == 0);
-    while (ip1 <= ilimit) {
-        u32 mLength;
-        u32 hash0 = zsa_hash(zsa_ld64(ip0), hlog, mls);
-        u32 const dictHashAndTag0 = zsa_hash(zsa_ld64(ip0), dictHBits, mls);
-        u32 dictMatchIndexAndTag = dictHashTable[dictHashAndTag0 >> 8];
-        int dictTagsMatch = (dictMatchIndexAndTag & 0xFF) == (dictHashAndTag0 & 0xFF);
-        u32 matchIndex = hashTable[hash0];
-        u32 curr = (u32)(ip0 - base);
-        u32 step = stepSize;
-        const u8* nextStep = ip0 + 256;
-        for (;;) {
-            const u8* match = base + matchIndex;
-            u32 const repIndex = curr + 1 - offset_1;
-            const u8* repMatch = (repIndex < prefixStartIndex) ? dictBase + (repIndex - dictIndexDelta) : base + repIndex;
-            u64 const v1 = zsa_ld64(ip1);
-            u32 const hash1 = zsa_hash(v1, hlog, mls);
-            u32 const dictHashAndTag1 = zsa_hash(v1, dictHBits, mls);
-            hashTable[hash0] = curr;
-            if (((u32)((prefixStartIndex - 1) - repIndex) >= 3) && (zsa_ld32(repMatch) == zsa_ld32(ip0 + 1))) {
-                const u8* const repMatchEnd = repIndex < prefixStartIndex ? dictEnd : iend;
-                mLength = zsa_count_2segments(ip0 + 1 + 4, repMatch + 4, iend, repMatchEnd, prefixStart) + 4;
-                ip0++;
-                seqOut[nbSeq++] = zsa_packseq((u32)(ip0 - anchor), mLength - ZSA_MINMATCH, 1);
-                break;
-            }
-            if (dictTagsMatch) {
-                u32 const dictMatchIndex = dictMatchIndexAndTag >> 8;
-                const u8* dictMatch = dictBase + dictMatchIndex;
-                if (dictMatchIndex > dictStartIndex && zsa_ld32(dictMatch) == zsa_ld32(ip0)) {
-                    if (matchIndex <= prefixStartIndex) {
-                        u32 const offset = (u32)(curr - dictMatchIndex - dictIndexDelta);
-                        mLength = zsa_count_2segments(ip0 + 4, dictMatch + 4, iend, dictEnd, prefixStart) + 4;
-                        while (((ip0 > anchor) & (dictMatch > dictStart)) && (ip0[-1] == dictMatch[-1])) { ip0--; dictMatch--; mLength++; }
-                        offset_2 = offset_1;
-                        offset_1 = offset;
-                        seqOut[nbSeq++] = zsa_packseq((u32)(ip0 - anchor), mLength - ZSA_MINMATCH, offset + 3);
-                        break;
-                    }
-                }
-            }
-            if (matchIndex > prefixStartIndex && zsa_ld32(match) == zsa_ld32(ip0)) {
-                u32 const offset = (u32)(ip0 - match);
-                mLength = zsa_count(ip0 + 4, match + 4, iend) + 4;
-                while (((ip0 > anchor) & (match > prefixStart)) && (ip0[-1] == match[-1])) { ip0--; match--; mLength++; }
-                offset_2 = offset_1;
-                offset_1 = offset;
-                seqOut[nbSeq++] = zsa_packseq((u32)(ip0 - anchor), mLength - ZSA_MINMATCH, offset + 3);
-                break;
-            }
-            dictMatchIndexAndTag = dictHashTable[dictHashAndTag1 >> 8];
-            dictTagsMatch = (dictMatchIndexAndTag & 0xFF) == (dictHashAndTag1 & 0xFF);
-            matchIndex = hashTable[hash1];
-            if (ip1 >= nextStep) { step++; nextStep += 256; }
-            ip0 = ip1;
-            ip1 = ip1 + step;
-            if (ip1 > ilimit) goto cleanup;
-            curr = (u32)(ip0 - base);
-            hash0 = hash1;
-        }
-        ip0 += mLength;
-        anchor = ip0;
-        if (ip0 <= ilimit) {
-            hashTable[zsa_hash(zsa_ld64(base + curr + 2), hlog, mls)] = curr + 2;
-            hashTable[zsa_hash(zsa_ld64(ip0 - 2), hlog, mls)] = (u32)(ip0 - 2 - base);
-            while (ip0 <= ilimit) {
-                u32 const current2 = (u32)(ip0 - base);
-                u32 const repIndex2 = current2 - offset_2;
-                const u8* repMatch2 = repIndex2 < prefixStartIndex ? dictBase - dictIndexDelta + repIndex2 : base + repIndex2;
-                if (((u32)((prefixStartIndex - 1) - repIndex2) >= 3) && (zsa_ld32(repMatch2) == zsa_ld32(ip0))) {
-                    const u8* const repEnd2 = repIndex2 < prefixStartIndex ? dictEnd : iend;
-                    u32 const repLength2 = zsa_count_2segments(ip0 + 4, repMatch2 + 4, iend, repEnd2, prefixStart) + 4;
-                    { u32 const t = offset_2; offset_2 = offset_1; offset_1 = t; }
-                    seqOut[nbSeq++] = zsa_packseq(0, repLength2 - ZSA_MINMATCH, 1);
-                    hashTable[zsa_hash(zsa_ld64(ip0), hlog, mls)] = current2;
-                    ip0 += repLength2;
-                    anchor = ip0;
-                    continue;
-                }
-                break;
-            }
-        }
-        ip1 = ip0 + stepSize;
-    }
-cleanup:
-    rep[0] = offset_1;
-    rep[1] = offset_2;
-    *lastLL = (u32)(iend - anchor);
-    return nbSeq;
-}
+#include "zsa_parse_dict.h"   // parse with an attached dictionary (zstd_fast.c:459-656), wave-level
 
 // ------------------------------------------------------------------ parse, dictionary as extDict (zstd_fast.c:685-936), serial
 // Returns 0xFFFFFFFF when the extDict has been invalidated for this block (zstd_fast.c:737-738): the caller
@@ -1574,8 +1343,8 @@ ZSA_DEV void zsa_gatherLiterals(ZsaEncShared* S, const u64* seq, u32 nbSeq, cons
 // Returns bytes written or (u64)-error (uniform).
 struct ZsaEncScratch { u64* seq; u8* lit; u8* tmp; ZsaFseCT* park; };   // park: 3 sequence tables (LL, OF, ML) of the last compressed block
 
-// FAMILY 0: ZSTD_dfast, and ZSTD_fast with a dictionary; FAMILY 1: ZSTD_greedy / ZSTD_lazy / ZSTD_lazy2; FAMILY 2: ZSTD_fast
-// without a dictionary (levels 1, 2 and below: the headline path).  Each is compiled into a kernel of its own: each parser
+// FAMILY 0: ZSTD_fast with a dictionary; FAMILY 1: ZSTD_greedy / ZSTD_lazy / ZSTD_lazy2; FAMILY 2: ZSTD_fast without a
+// dictionary (levels 1, 2 and below: the headline path); FAMILY 3: ZSTD_dfast.  Each is compiled into a kernel of its own: each parser
 // then gets the whole register budget (one kernel holding two of them spilled).
 template <int FAMILY>
 ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams& P, const u8* src, u64 srcSize64,
@@ -1727,12 +1496,30 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
                 if (curr > LZ.nextToUpdate + 384) { u32 const gap = curr - LZ.nextToUpdate - 384; LZ.nextToUpdate = curr - (gap < 192 ? gap : 192); }
             }
             bool const dictParse = FAMILY == 0 && ((Wn.lowLimit < Wn.dictLimit) || (Wn.dms != nullptr));
-            if (dictParse && lane == 0) {   // dictionary variants: serial (small payloads; many frames in flight instead)
+            if (dictParse && !(Wn.lowLimit < Wn.dictLimit)) {   // attached dictionary: wave-level parse (zsa_parse_dict.h)
+                // its bitmap takes LDS of the entropy stages: the Huffman table at hand (the dictionary's, for the first block)
+                // waits in global scratch meanwhile
+                u32* const park = (u32*)W.tmp;
+                for (u32 i = (u32)lane; i < sizeof(ZsaHufCT) / 4; i += ZSA_WAVE) park[i] = ((const u32*)&S->hufPrev)[i];
+                wv_sync();
+                for (u32 i = (u32)lane; i < sizeof(S->dupBits) / 4; i += ZSA_WAVE) S->dupBits[i] = 0;
+                wv_sync();
+                if (lane == 0) { S->nextRep[0] = S->prevRep[0]; S->nextRep[1] = S->prevRep[1]; S->nextRep[2] = S->prevRep[2]; }
+                wv_sync();
+                u32* const io = &S->u[EU_s0];   // offsets in and out, last literal run out
+                if (lane == 0) { io[0] = S->prevRep[0]; io[1] = S->prevRep[1]; io[2] = 0; }
+                wv_sync();
+                u32 const nbSeq = wv_uniform(zsa_parse_dms_wave(hashTable, P.hlog, P.mml, P.tlen, Wn.base, Wn.dictLimit, Wn.dms, ip, blockSize, io, W.seq, S->dupBits));
+                wv_sync();
+                for (u32 i = (u32)lane; i < sizeof(ZsaHufCT) / 4; i += ZSA_WAVE) ((u32*)&S->hufPrev)[i] = park[i];
+                if (lane == 0) {
+                    S->nextRep[0] = io[0]; S->nextRep[1] = io[1];
+                    S->u[EU_nbSeq] = nbSeq; S->u[EU_lastLL] = io[2];
+                }
+            } else if (dictParse && lane == 0) {   // dictionary as extDict: serial (payloads above 8 KiB with a dictionary)
                 u32 rep[3] = { S->prevRep[0], S->prevRep[1], S->prevRep[2] };
                 u32 lastLL = 0;
-                u32 nbSeq = 0xFFFFFFFFu;   // zstd_compress_internal.h:971-978 ZSTD_matchState_dictMode
-                if (Wn.lowLimit < Wn.dictLimit) nbSeq = zsa_parse_fast_ext(hashTable, P, Wn, ip, blockSize, rep, W.seq, &lastLL);
-                else nbSeq = zsa_parse_fast_dms(hashTable, P, Wn, ip, blockSize, rep, W.seq, &lastLL);
+                u32 const nbSeq = zsa_parse_fast_ext(hashTable, P, Wn, ip, blockSize, rep, W.seq, &lastLL);   // 0xFFFFFFFF: extDict invalidated
                 S->nextRep[0] = rep[0]; S->nextRep[1] = rep[1]; S->nextRep[2] = rep[2];
                 S->u[EU_nbSeq] = nbSeq; S->u[EU_lastLL] = lastLL;
             }
@@ -1743,14 +1530,9 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
                 u32 lastLL = 0, nbSeq;
                 if (FAMILY == 1) {   // greedy / lazy / lazy2 (never with a dictionary here): wave-uniform, zsa_lazy.h
                     nbSeq = zsa_parse_lazy(LZ, Wn.dictLimit, ip, blockSize, P.strat - 3, rep, W.seq, &lastLL, lane);
-                } else if (FAMILY == 0 && P.strat == 2) {   // ZSTD_dfast (never with a dictionary here): serial for now, zsa_dfast.h
+                } else if (FAMILY == 3) {   // ZSTD_dfast (never with a dictionary here): serial for now, zsa_dfast.h
                     nbSeq = 0;
                     if (lane == 0) nbSeq = zsa_parse_dfast(hashTable, hashTable + (1u << P.hlog), P, Wn.base, Wn.dictLimit, ip, blockSize, rep, W.seq, &lastLL);
-                    nbSeq = wv_shfl(nbSeq, 0); lastLL = wv_shfl(lastLL, 0);
-                    rep[0] = wv_shfl(rep[0], 0); rep[1] = wv_shfl(rep[1], 0);
-                } else if (FAMILY == 0 && Wn.loadedDictEnd != 0) {   // contiguous-dictionary corner (extDict too small): serial plain parser
-                    nbSeq = 0;
-                    if (lane == 0) nbSeq = zsa_parse_fast(hashTable, P, Wn.base, Wn.dictLimit, Wn.loadedDictEnd, ip, blockSize, rep, W.seq, &lastLL);
                     nbSeq = wv_shfl(nbSeq, 0); lastLL = wv_shfl(lastLL, 0);
                     rep[0] = wv_shfl(rep[0], 0); rep[1] = wv_shfl(rep[1], 0);
                 } else {   // ZSTD_fast without a dictionary segment: the wave parser (zsa_parse.h)
@@ -1770,9 +1552,10 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
                         }
                         for (u32 i = (u32)lane; i < sizeof(S->dupBits) / 4; i += ZSA_WAVE) S->dupBits[i] = 0;
                         wv_sync();
-                        nbSeq = zsa_parse_fast_block(hashTable, S->filt, S->dupBits, S->ring, S->tags, P, Wn.base, Wn.dictLimit, ip, blockSize, rep, W.seq, &lastLL, fpPosBits, lane);
+                        nbSeq = zsa_parse_fast_block(hashTable, S->filt, S->dupBits, S->ring, S->tags, P, Wn.base, Wn.dictLimit, ip, blockSize, rep, W.seq, &lastLL, fpPosBits, false, lane);
                     } else {
-                        nbSeq = zsa_parse_fast_block(hashTable, nullptr, nullptr, S->ring, S->tags, P, Wn.base, Wn.dictLimit, ip, blockSize, rep, W.seq, &lastLL, fpPosBits, lane);
+                        // (a dictionary loaded contiguously below the block -- extDict too small to keep -- only widens the prefix)
+                        nbSeq = zsa_parse_fast_block(hashTable, nullptr, nullptr, S->ring, S->tags, P, Wn.base, Wn.dictLimit, ip, blockSize, rep, W.seq, &lastLL, fpPosBits, Wn.loadedDictEnd != 0, lane);
                     }
                     wv_sync();
                     for (u32 i = (u32)lane; i < sizeof(ZsaHufCT) / 4; i += ZSA_WAVE) ((u32*)&S->hufPrev)[i] = park[i];
@@ -1799,7 +1582,7 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
             wv_sync();
             ZSA_PROF(S, lane, 2);
             // (FAMILY 0: the strategy is 1 or 2, which folds the cost-based mode selection out of that kernel)
-            u32 const strat = FAMILY == 2 ? 1u : (FAMILY == 0 ? (P.strat == 2 ? 2u : 1u) : P.strat);
+            u32 const strat = (FAMILY == 2 || FAMILY == 0) ? 1u : (FAMILY == 3 ? 2u : P.strat);
             cSize = zsa_entropyCompress(S, W.seq, nbSeq, W.lit, litSize, op + 3, blockSize, W.tmp, literalsDisabled, cd, strat,
                                         (FAMILY == 1 && P.strat >= 4 && !cd) ? W.park : (const ZsaFseCT*)0, lane);
             if (S->err) return ZSA_ERR(S->err);

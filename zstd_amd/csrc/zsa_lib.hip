@@ -105,12 +105,12 @@ ZSA_DEV void zsa_compress_body(ZsaEncShared& S, u32& nextFrame, const ZsaFrameDe
         // (a frame larger than the launch was sized for -- sizes linked on the device -- is refused rather than overrun)
         bool const unsupported = bad || !(cp.strat == 1 || (cp.strat >= 2 && cp.strat <= 5 && !cd)) || tableBytes > L.htBytes
                               || (d.srcSize > L.blockCap && L.blockCap < ZSA_BLOCKSIZE_MAX);
-        int const fam = cd ? 0 : (cp.strat == 1 ? 2 : (cp.strat == 2 ? 0 : 1));
+        int const fam = cd ? 0 : (cp.strat == 1 ? 2 : (cp.strat == 2 ? 3 : 1));
         if (unsupported || !((famMask >> fam) & 1)) {
             if (reporter && threadIdx.x == 0) results[f] = ZSA_ERR(ZSA_parameter_unsupported);
         } else if (fam == FAMILY) {
             ZsaEncParams P; P.wlog = cp.wlog; P.hlog = cp.hlog; P.mml = cp.mml; P.tlen = cp.tlen; P.clog = cp.clog; P.strat = cp.strat; P.slog = cp.slog;
-            u64 const r = zsa_encode_frame<FAMILY>(&S, zsa_hashTable, P, d.src, d.srcSize, d.dst, d.dstCapacity, W, FAMILY == 0 ? cd : (const ZsaCDictDev*)nullptr, dictMode);
+            u64 const r = zsa_encode_frame<FAMILY>(&S, zsa_hashTable, P, d.src, d.srcSize, d.dst, d.dstCapacity, W, FAMILY == 0 ? cd : (const ZsaCDictDev*)nullptr, FAMILY == 0 ? dictMode : (int)zsa_dm_none);
             if (threadIdx.x == 0) results[f] = r;
         }
         __syncthreads();
@@ -131,10 +131,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZSA_ENC
 zsa_k_compress_dict(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
                     u32* __restrict__ counter, u8* __restrict__ scratch, const ZsaEncLayout L, int level, const ZsaCDictDev* cd, int famMask, int reporter,
                     u64* __restrict__ prof)
-{   // ZSTD_dfast, and ZSTD_fast with a dictionary
+{   // ZSTD_fast with a dictionary (BulkProcessor)
     __shared__ ZsaEncShared S;
     __shared__ u32 nextFrame;
     zsa_compress_body<0>(S, nextFrame, frames, results, nFrames, counter, scratch, L, level, cd, famMask, reporter, prof);
+}
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZSA_ENC_WAVES, ZSA_ENC_WAVES)))
+zsa_k_compress_dfast(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
+                     u32* __restrict__ counter, u8* __restrict__ scratch, const ZsaEncLayout L, int level, int famMask, int reporter,
+                     u64* __restrict__ prof)
+{   // ZSTD_dfast
+    __shared__ ZsaEncShared S;
+    __shared__ u32 nextFrame;
+    zsa_compress_body<3>(S, nextFrame, frames, results, nFrames, counter, scratch, L, level, nullptr, famMask, reporter, prof);
 }
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZSA_ENC_WAVES, ZSA_ENC_WAVES)))
 zsa_k_compress_lazy(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
@@ -420,10 +429,10 @@ extern "C" size_t zsa_compress_enqueue(zsa_batch* b, int level, const zsa_CDict*
     }
     HIPCHK(hipMemsetAsync(b->d_counter, 0, 256, (hipStream_t)stream));
     // which parser families the level's clevels.h rows can resolve to: a dictionary -> family 0; ZSTD_fast at levels <= 2
-    // (level 0 means 3); ZSTD_dfast at levels 2-4; ZSTD_greedy/ZSTD_lazy/ZSTD_lazy2 from level 4 on
+    // (level 0 means 3) -> family 2; ZSTD_dfast at levels 2-4 -> family 3; ZSTD_greedy/ZSTD_lazy/ZSTD_lazy2 from level 4 on -> family 1
     int const lv = level == 0 ? 3 : level;
-    bool const fam2 = !cdict && lv <= 2, fam0 = cdict || (lv >= 2 && lv <= 4), fam1 = !cdict && lv >= 4;
-    int const famMask = (fam0 ? 1 : 0) | (fam1 ? 2 : 0) | (fam2 ? 4 : 0);
+    bool const fam0 = cdict != nullptr, fam2 = !cdict && lv <= 2, fam3 = !cdict && lv >= 2 && lv <= 4, fam1 = !cdict && lv >= 4;
+    int const famMask = (fam0 ? 1 : 0) | (fam1 ? 2 : 0) | (fam2 ? 4 : 0) | (fam3 ? 8 : 0);
     const ZsaCDictDev* const cd = cdict ? (const ZsaCDictDev*)cdict->d_cd : (const ZsaCDictDev*)nullptr;
     u64* const prof = b->profOn ? b->d_prof : (u64*)nullptr;
     // (same scratch: the launches run one after the other on the stream; the first one reports unsupported frames)
@@ -436,6 +445,11 @@ extern "C" size_t zsa_compress_enqueue(zsa_batch* b, int level, const zsa_CDict*
     if (fam0) {
         hipLaunchKernelGGL(zsa_k_compress_dict, dim3(grid), dim3(64), 0, (hipStream_t)stream,
                            b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter, b->d_encScratch, L, level, cd, famMask, reporter, prof);
+        reporter = 0;
+    }
+    if (fam3) {
+        hipLaunchKernelGGL(zsa_k_compress_dfast, dim3(grid), dim3(64), 0, (hipStream_t)stream,
+                           b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter + 48, b->d_encScratch, L, level, famMask, reporter, prof);
         reporter = 0;
     }
     if (fam1)

@@ -51,6 +51,7 @@ struct ZsaRing {
     const u8* src;         // frame start
     u32 lo, hi;            // ring holds frame offsets [lo, hi)
     u32 limit;             // no byte at or beyond this frame offset is ever read (end of the block being parsed)
+    u32 min;               // ... nor below this one (a frame that follows a dictionary in index space starts above 0)
 };
 struct __attribute__((packed)) ZsaPk64 { u64 v; };
 struct __attribute__((packed)) ZsaPk32 { u32 v; };
@@ -71,8 +72,8 @@ ZSA_DEV void zsa_ring_fill(ZsaRing& R, u32 want, int lane)
     while (R.hi < want && R.hi < R.limit) {
         u32 const o = R.hi + 16u * (u32)lane;
         u32 v[4] = { 0, 0, 0, 0 };
-        if (o + 16 <= R.limit) { v[0] = wv_ldg32(R.src + o); v[1] = wv_ldg32(R.src + o + 4); v[2] = wv_ldg32(R.src + o + 8); v[3] = wv_ldg32(R.src + o + 12); }
-        else if (o < R.limit) { for (u32 k = 0; k < R.limit - o; k++) v[k >> 2] |= wv_ldg8(R.src + o + k) << (8 * (k & 3)); }
+        if (o + 16 <= R.limit && o >= R.min) { v[0] = wv_ldg32(R.src + o); v[1] = wv_ldg32(R.src + o + 4); v[2] = wv_ldg32(R.src + o + 8); v[3] = wv_ldg32(R.src + o + 12); }
+        else if (o < R.limit && o + 16 > R.min) { for (u32 k = 0; k < 16; k++) if (o + k >= R.min && o + k < R.limit) v[k >> 2] |= wv_ldg8(R.src + o + k) << (8 * (k & 3)); }
         u32 const ro = o & (ZSA_RING_BYTES - 1);
         u32* const d = (u32*)(R.b + ro);
         d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
@@ -233,6 +234,7 @@ ZSA_DEV void zsa_extend16(const ZsaRing& R, u32 ip, u32 m, u32 iend, u32 ipB, u3
 struct ZsaParseCtx {      // constants of the block
     const u8* base; u64* seqOut;
     u32 hlog, posBits, stepSize, iend, ilimit, prefixStartIndex;
+    u32 ringMin;          // lowest frame offset the source ring may load (see ZsaRing::min)
 };
 struct ZsaParseState {
     u32 ip0, anchor, rep1, rep2, nbSeq;
@@ -268,7 +270,7 @@ ZSA_DEV void zsa_parse_general_body(const TAB T, u32* ringWords, u8* tags, const
     bool const useFp = posBits != 0;
     u32 const posMask = useFp ? ((1u << posBits) - 1u) : 0xFFFFFFFFu;
     ZsaRing R;
-    R.b = (u8*)ringWords; R.src = C.base + 2; R.limit = iend - 2; R.lo = wv_uniform(st.rlo); R.hi = wv_uniform(st.rhi);
+    R.b = (u8*)ringWords; R.src = C.base + 2; R.limit = iend - 2; R.min = C.ringMin; R.lo = wv_uniform(st.rlo); R.hi = wv_uniform(st.rhi);
     u32 anchor = wv_uniform(st.anchor), ip0 = wv_uniform(st.ip0);
     u32 rep1 = wv_uniform(st.rep1), rep2 = wv_uniform(st.rep2), nbSeq = wv_uniform(st.nbSeq);
     bool resume = wv_uniform(st.midEpisode) != 0;
@@ -521,12 +523,12 @@ ZSA_DEVFN void zsa_parse_general(const TAB T, u32* ringWords, u8* tags, const Zs
 // continuation of a match that ran past the first round of zsa_chunk_extend (rare: kept out of line)
 ZSA_DEVFN u32 zsa_count_far(const u8* ringB, const u8* src, u32 lo, u32 hi, u32 limit, u32 ip, u32 m, u32 iend)
 {
-    ZsaRing R; R.b = (u8*)ringB; R.src = src; R.lo = lo; R.hi = hi; R.limit = limit;
+    ZsaRing R; R.b = (u8*)ringB; R.src = src; R.lo = lo; R.hi = hi; R.limit = limit; R.min = 0;
     return zsa_count_wave(R, ip, m, iend, wv_lane());
 }
 ZSA_DEVFN u32 zsa_back_far(const u8* ringB, const u8* src, u32 lo, u32 hi, u32 limit, u32 ipB, u32 mB, u32 maxBack)
 {   // zstd_fast.c:285-289 beyond the first 16 bytes, 64 bytes per step
-    ZsaRing R; R.b = (u8*)ringB; R.src = src; R.lo = lo; R.hi = hi; R.limit = limit;
+    ZsaRing R; R.b = (u8*)ringB; R.src = src; R.lo = lo; R.hi = hi; R.limit = limit; R.min = 0;
     int const lane = wv_lane();
     u32 nb = 16;
     while (nb < maxBack) {
@@ -556,7 +558,7 @@ ZSA_DEVFN u32 zsa_back_far(const u8* ringB, const u8* src, u32 lo, u32 hi, u32 l
 // ring fill out of line (about once per KiB of input): returns the new R.hi
 ZSA_DEVFN u32 zsa_ring_fill_far(u8* ringB, const u8* src, u32 hi, u32 want, u32 limit)
 {
-    ZsaRing R; R.b = ringB; R.src = src; R.lo = 0; R.hi = hi; R.limit = limit;
+    ZsaRing R; R.b = ringB; R.src = src; R.lo = 0; R.hi = hi; R.limit = limit; R.min = 0;
     if (want > hi + 2 * ZSA_RING_BYTES) R.hi = (want - ZSA_RING_BYTES) & ~1023u;   // a long match: nothing of what it skipped is read again through the ring
     zsa_ring_fill(R, want, wv_lane());
     return R.hi;
@@ -576,7 +578,7 @@ ZSA_DEVFN void zsa_parse_chunk(const ZsaTabFilt T, u32* ringWords, const ZsaPars
     u32 const safeEnd = iend > 288 ? iend - 288 : 0;            // chunks start at or below it: every lane's 8 bytes, all pairs and the
                                                                 // first extension round then lie inside the block
     ZsaRing R;
-    R.b = (u8*)ringWords; R.src = (const u8*)wv_uniform64((u64)C.base) + 2; R.limit = iend - 2; R.lo = wv_uniform(st.rlo); R.hi = wv_uniform(st.rhi);
+    R.b = (u8*)ringWords; R.src = (const u8*)wv_uniform64((u64)C.base) + 2; R.limit = iend - 2; R.min = 0; R.lo = wv_uniform(st.rlo); R.hi = wv_uniform(st.rhi);
     u32 ip0 = wv_uniform(st.ip0), anchor = wv_uniform(st.anchor), rep1 = wv_uniform(st.rep1), rep2 = wv_uniform(st.rep2), nbSeq = wv_uniform(st.nbSeq);
     u32 chk = wv_uniform(st.chkRep2), mid = wv_uniform(st.midEpisode);
     u32 nextStep = mid ? wv_uniform(st.nextStep) : ip0 + 128;
@@ -771,18 +773,21 @@ ZSA_DEVFN void zsa_parse_chunk(const ZsaTabFilt T, u32* ringWords, const ZsaPars
 // Parses one block.  T: the frame's match table in the workgroup's global scratch.  base: window base (index i <-> base + i, the
 // frame starts at index 2).  Returns the number of sequences appended to seqOut; rep[] and *lastLL are updated.  All values
 // are wave-uniform.  filt / dup: LDS words of the chunk path (null: general evaluation only).
+// wholePrefix: a dictionary is loaded right below the block in index space (contiguously, so no extDict segment): the window
+// does not limit the prefix (ZSTD_getLowestPrefixIndex with loadedDictEnd != 0) and nothing below the block is read.
 template <int MLS>
 ZSA_DEV u32 zsa_parse_fast_blockT(u32* T, u32* filt, u32* dup, u32* ringWords, u8* tags, const ZsaEncParams& P, const u8* base, u32 dictLimit,
-                                  const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL, u32 posBits, int lane)
+                                  const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL, u32 posBits, bool wholePrefix, int lane)
 {
     ZsaParseCtx C;
     C.base = base; C.seqOut = seqOut; C.hlog = P.hlog; C.posBits = posBits;
     C.stepSize = (P.tlen > 1) ? (P.tlen + 1) : 2;               // zstd_fast.c:153, :429
     u32 const istart = (u32)(src - base);
     C.iend = istart + srcSize; C.ilimit = C.iend - 8;           // indices
-    u32 const maxDistance = 1u << P.wlog;
-    // ZSTD_getLowestPrefixIndex (zstd_compress_internal.h:1307-1318), no loaded dictionary
+    u32 const maxDistance = wholePrefix ? 0xFFFFFFFFu : 1u << P.wlog;
+    // ZSTD_getLowestPrefixIndex (zstd_compress_internal.h:1307-1318)
     C.prefixStartIndex = (C.iend - dictLimit > maxDistance) ? C.iend - maxDistance : dictLimit;
+    C.ringMin = wholePrefix ? istart - 2 : 0;
     ZsaParseState st;
     st.anchor = istart; st.ip0 = istart + (istart == C.prefixStartIndex);
     st.rep1 = rep[0]; st.rep2 = rep[1]; st.nbSeq = 0; st.chkRep2 = 0; st.nextStep = 0; st.midEpisode = 0; st.done = 0;
@@ -819,12 +824,12 @@ ZSA_DEV u32 zsa_parse_fast_blockT(u32* T, u32* filt, u32* dup, u32* ringWords, u
 #undef ZSA_FPV
 
 ZSA_DEV u32 zsa_parse_fast_block(u32* T, u32* filt, u32* dup, u32* ringWords, u8* tags, const ZsaEncParams& P, const u8* base, u32 dictLimit,
-                                 const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL, u32 posBits, int lane)
+                                 const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL, u32 posBits, bool wholePrefix, int lane)
 {
     switch (P.mml) {
-    case 5:  return zsa_parse_fast_blockT<5>(T, filt, dup, ringWords, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
-    case 6:  return zsa_parse_fast_blockT<6>(T, filt, dup, ringWords, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
-    case 7:  return zsa_parse_fast_blockT<7>(T, filt, dup, ringWords, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
-    default: return zsa_parse_fast_blockT<4>(T, filt, dup, ringWords, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, lane);
+    case 5:  return zsa_parse_fast_blockT<5>(T, filt, dup, ringWords, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, wholePrefix, lane);
+    case 6:  return zsa_parse_fast_blockT<6>(T, filt, dup, ringWords, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, wholePrefix, lane);
+    case 7:  return zsa_parse_fast_blockT<7>(T, filt, dup, ringWords, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, wholePrefix, lane);
+    default: return zsa_parse_fast_blockT<4>(T, filt, dup, ringWords, tags, P, base, dictLimit, src, srcSize, rep, seqOut, lastLL, posBits, wholePrefix, lane);
     }
 }

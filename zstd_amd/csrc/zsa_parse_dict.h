@@ -1,0 +1,201 @@
+// zsa_parse_dict.h -- the ZSTD_fast parse against an ATTACHED dictionary (zstd_fast.c:459-656: payloads of up to 8 KiB with a
+// CDict, the BulkProcessor path), executed by all 64 lanes of the wave.
+//
+// The reference visits positions one by one (step 1, growing by one every 256 bytes without a match) and per position p
+// performs, in this order: insert p into the local table; a repcode check at p + 1; a check against the dictionary's
+// tagged table (only taken when the local table has nothing valid for p); a check against the local table.  Here a WINDOW
+// is up to 64 consecutive positions, lane k <-> position ip0 + k:
+//   * every lane hashes its position twice (local table, dictionary table + 8 tag bits), reads both cells and makes its
+//     three checks; lane order == position order and rep > dictionary > local inside a lane, so the first lane of one
+//     ballot with any hit is the event the reference stops at;
+//   * a lane's local probe is exact as long as no earlier lane of the window falls into the same cell; the lanes that share
+//     a cell are found with a bitmap pass over the cell numbers and the window is cut below the second-lowest of them;
+//   * dictionary and payload form one index space (dictionary bytes sit right below prefixStartIndex), so a match that
+//     starts in the dictionary and runs on into the payload -- ZSTD_count_2segments -- is one forward count, 64 bytes per step;
+//   * positions up to the event enter the local table in one store (distinct cells), then current + 2 and ip0 - 2.
+// Included by zsa_encode.h (uses zsa_hash, zsa_packseq, ZsaEncParams, ZsaCDictDev, ZsaWindow from there).
+#pragma once
+
+struct ZsaDmsView {       // one index space over dictionary + payload
+    const u8* base;       // index i >= prefix <-> base + i
+    const u8* dbase;      // index i <  prefix <-> dbase + i   (dictionary content, shifted by dictIndexDelta)
+    u32 prefix;           // prefixStartIndex
+    u32 dictLow;          // lowest dictionary index (dictStartIndex + dictIndexDelta)
+};
+ZSA_DEV u32 zsa_dv8(const ZsaDmsView& V, u32 i) { return i >= V.prefix ? wv_ldg8(V.base + i) : wv_ldg8(V.dbase + i); }
+// 4 bytes at index i; the callers guarantee that [i, i + 4) does not straddle the prefix start
+ZSA_DEV u32 zsa_dv32(const ZsaDmsView& V, u32 i) { return i >= V.prefix ? wv_ldg32(V.base + i) : wv_ldg32(V.dbase + i); }
+
+// common length of [ip, iend) and [m, ...) in the joint index space, m < ip (ZSTD_count / ZSTD_count_2segments,
+// zstd_compress_internal.h:755-793); uniform arguments, all lanes
+ZSA_DEV u32 zsa_dv_count(const ZsaDmsView& V, u32 ip, u32 m, u32 iend, int lane)
+{
+    u32 total = 0;
+    for (;;) {
+        u32 const a = ip + total + (u32)lane;
+        bool const same = a < iend && wv_ldg8(V.base + a) == zsa_dv8(V, m + total + (u32)lane);
+        u64 const stop = wv_ballot(!same);
+        if (stop) return total + (u32)__builtin_ctzll(stop);
+        total += ZSA_WAVE;
+    }
+}
+// bytes that match backwards from (ip - 1, m - 1): ip stays above `anchor`, m above `low` (zstd_fast.c:569-573, :583-588)
+ZSA_DEV u32 zsa_dv_back(const ZsaDmsView& V, u32 ip, u32 m, u32 anchor, u32 low, int lane)
+{
+    u32 const room = (ip - anchor) < (m - low) ? (ip - anchor) : (m - low);
+    u32 total = 0;
+    while (total < room) {
+        u32 const k = total + (u32)lane;
+        bool const same = k < room && wv_ldg8(V.base + ip - 1 - k) == zsa_dv8(V, m - 1 - k);
+        u64 const stop = wv_ballot(!same);
+        if (stop) return total + (u32)__builtin_ctzll(stop);
+        total += ZSA_WAVE;
+    }
+    return total;
+}
+
+// Parses one block with the dictionary `Wn.dms` attached.  hashTable: the frame's local table (global scratch, zeroed).
+// dup: LDS words, all zero, at least 256 (a bitmap over cell numbers modulo 8192).  Returns the number of sequences
+// appended to seqOut; rep[] and *lastLL are updated.  All values are wave-uniform.  (A function of its own, so that its loop
+// gets its own register allocation: inlined into the frame encoder it ran out of spilled registers.)
+ZSA_DEVFN u32 zsa_parse_dms_wave(u32* hashTable, u32 hlog, u32 mls, u32 tlen, const u8* wbase, u32 wDictLimit, const ZsaCDictDev* dms,
+                                 const u8* src, u32 srcSize, u32* rep /* LDS: [0], [1] in and out, [2] receives the last literal run */,
+                                 u64* seqOut, u32* dup)
+{
+    int const lane = wv_lane();
+    hlog = wv_uniform(hlog); mls = wv_uniform(mls); srcSize = wv_uniform(srcSize);
+    u32 const stepSize = wv_uniform(tlen + !tlen);              // zstd_fast.c:470
+    struct { const u8* base; u32 dictLimit; } Wn;
+    Wn.base = (const u8*)wv_uniform64((u64)wbase); Wn.dictLimit = wv_uniform(wDictLimit);
+    dms = (const ZsaCDictDev*)wv_uniform64((u64)dms);
+    seqOut = (u64*)wv_uniform64((u64)seqOut); hashTable = (u32*)wv_uniform64((u64)hashTable);
+    src = (const u8*)wv_uniform64((u64)src);
+    const u32* const dictTable = dms->hashTable;
+    u32 const dictHBits = dms->cp.hlog + 8;                     // 8 tag bits (:21)
+    u32 const prefix = Wn.dictLimit;
+    u32 const dictEndIndex = 2 + dms->contentSize;              // the dictionary's own indices run from 2 (window start) to its end
+    u32 const dictIndexDelta = prefix - dictEndIndex;           // :484
+    ZsaDmsView V;
+    V.base = Wn.base; V.dbase = (dms->content - 2) - dictIndexDelta; V.prefix = prefix; V.dictLow = 2 + dictIndexDelta;
+    u32 const istart = (u32)(src - Wn.base), iend = istart + srcSize, ilimit = iend - 8;
+    u32 ip0 = istart, anchor = istart;
+    u32 off1 = wv_uniform(rep[0]), off2 = wv_uniform(rep[1]), nbSeq = 0;
+    ip0 += ((istart - prefix) + dms->contentSize == 0);         // :497 dictAndPrefixLength == 0
+    u32 step = stepSize, nextStep = ip0 + 256;                  // :533, kStepIncr = 1 << 8
+    if (srcSize >= 8 + stepSize)   // (ilimit does not wrap)
+    for (;;) {   // one window per iteration
+        // positions: consecutive while the step is 1, up to and including the first one at or beyond nextStep (whose own
+        // step is 2); beyond that one position per window
+        u32 nAct = 1;
+        if (step == 1) { u32 const a = nextStep - ip0 + 1; nAct = a < ZSA_WAVE ? a : ZSA_WAVE; }
+        u32 const cur = ip0 + (u32)lane;
+        u32 const myStep = step + ((lane > 0 && cur >= nextStep) ? 1u : 0u);
+        bool const valid = (u32)lane < nAct && cur + myStep <= ilimit;       // the reference reaches it (:530, :618)
+        u32 nEff = (u32)__builtin_popcountll(wv_ballot(valid));              // (a prefix of the lanes)
+        if (nEff == 0) break;
+        bool ends = nEff < nAct;
+        u64 v = 0; u32 h = 0, mIdx = 0, dcell = 0, dh = 0;
+        if (valid) {
+            v = wv_ldg64(V.base + cur);
+            h = zsa_hash(v, hlog, mls);
+            dh = zsa_hash(v, dictHBits, mls);
+            mIdx = wv_ldg_cell(hashTable + h);
+            dcell = wv_ldg_cell(dictTable + (dh >> 8));
+        }
+        {   // lanes that share their local cell with another lane of the window: cut the window below the second-lowest
+            u32* const dw = dup + ((h >> 5) & 255u);
+            u32 const bit = 1u << (h & 31u);
+            bool late = false;
+            if (valid) late = (wv_atomic_or_lds(dw, bit) & bit) != 0;
+            wv_lds_fence();
+            if (late) (void)wv_atomic_and_lds(dw, ~bit);
+            wv_lds_fence();
+            bool const shares = valid && (late || !(*dw & bit));
+            wv_lds_fence();
+            if (valid) *dw = 0;
+            wv_lds_fence();
+            u64 const G = wv_ballot(shares);
+            u64 const G2 = G & (G - 1);
+            if (G2) { u32 const w = (u32)__builtin_ctzll(G2); if (w < nEff) { nEff = w; ends = false; } }   // (w >= 1)
+        }
+        bool const mine = (u32)lane < nEff;
+        // the three checks of a position (:536-592)
+        u32 kind = 0;   // 1: repcode at cur + 1, 2: dictionary, 3: local table
+        if (mine) {
+            u32 const repIndex = cur + 1 - off1;
+            u32 const w0 = (u32)v, w1 = (u32)(v >> 8);
+            if ((u32)((prefix - 1) - repIndex) >= 3 && zsa_dv32(V, repIndex) == w1) kind = 1;
+            else {
+                bool const tagsMatch = (dcell & 0xFFu) == (dh & 0xFFu);
+                u32 const dIdx = dcell >> 8;
+                if (tagsMatch && dIdx > 2 && mIdx <= prefix && wv_ldg32(dms->content - 2 + dIdx) == w0) kind = 2;
+                else if (mIdx > prefix && wv_ldg32(V.base + mIdx) == w0) kind = 3;
+            }
+        }
+        u64 const found = wv_ballot(kind != 0);
+        u32 const nIns = found ? (u32)__builtin_ctzll(found) + 1 : nEff;     // positions that enter the local table (:535)
+        if ((u32)lane < nIns) wv_stg_cell(hashTable + h, cur);               // (distinct cells: the window was cut)
+        wv_lds_fence();
+        if (!found) {
+            if (ends) break;
+            // the step after the last position of the window (:613-618)
+            u32 const last = ip0 + nEff - 1;
+            u32 const s = step + ((nEff > 1 && last >= nextStep) ? 1u : 0u);   // the step that position was reached with
+            if (s != step) { step = s; nextStep += 256; }
+            ip0 = last + step;
+            if (ip0 >= nextStep) { step++; nextStep += 256; }
+            continue;
+        }
+        int const e = __builtin_ctzll(found);
+        u32 const eKind = wv_readlane(kind, e), curE = ip0 + (u32)e;
+        u32 start, mLength, offcode;
+        if (eKind == 1) {
+            start = curE + 1;
+            mLength = zsa_dv_count(V, start + 4, start - off1 + 4, iend, lane) + 4;
+            offcode = 1;
+        } else {
+            u32 const m = eKind == 2 ? (wv_readlane(dcell, e) >> 8) + dictIndexDelta : wv_readlane(mIdx, e);
+            u32 const low = eKind == 2 ? V.dictLow : prefix;
+            u32 const fwd = zsa_dv_count(V, curE + 4, m + 4, iend, lane);
+            u32 const bwd = zsa_dv_back(V, curE, m, anchor, low, lane);
+            start = curE - bwd;
+            mLength = 4 + fwd + bwd;
+            off2 = off1; off1 = curE - m;
+            offcode = off1 + 3;
+        }
+        if (lane == 0) wv_stg64(seqOut + nbSeq, zsa_packseq(start - anchor, mLength - ZSA_MINMATCH, offcode));
+        nbSeq++;
+        ip0 = start + mLength;
+        anchor = ip0;
+        if (ip0 <= ilimit) {
+            {   // :599-601: current + 2, then ip0 - 2
+                u32 const pp = lane == 0 ? curE + 2 : ip0 - 2;
+                u32 hh = 0;
+                if (lane < 2) hh = zsa_hash(wv_ldg64(V.base + pp), hlog, mls);
+                if (lane == 0) wv_stg_cell(hashTable + hh, pp);
+                wv_lds_fence();
+                if (lane == 1) wv_stg_cell(hashTable + hh, pp);
+                wv_lds_fence();
+            }
+            while (ip0 <= ilimit) {   // :603-620: the second offset, immediately and repeatedly
+                u32 const repIndex2 = ip0 - off2;
+                if (!((u32)((prefix - 1) - repIndex2) >= 3)) break;
+                if (wv_uniform(zsa_dv32(V, repIndex2)) != wv_uniform(wv_ldg32(V.base + ip0))) break;
+                u32 const len = zsa_dv_count(V, ip0 + 4, repIndex2 + 4, iend, lane) + 4;
+                { u32 const t = off2; off2 = off1; off1 = t; }
+                if (lane == 0) {
+                    wv_stg64(seqOut + nbSeq, zsa_packseq(0, len - ZSA_MINMATCH, 1));
+                    wv_stg_cell(hashTable + zsa_hash(wv_ldg64(V.base + ip0), hlog, mls), ip0);
+                }
+                wv_lds_fence();
+                nbSeq++;
+                ip0 += len;
+                anchor = ip0;
+            }
+        }
+        step = stepSize; nextStep = ip0 + 256;                  // :530-533 a new search
+        if (ip0 + step > ilimit) break;
+    }
+    if (lane == 0) { rep[0] = off1; rep[1] = off2; rep[2] = iend - anchor; }   // :625-629 (no offset is ever set aside in this variant)
+    return wv_uniform(nbSeq);
+}
