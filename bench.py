@@ -369,9 +369,8 @@ def main():
         algo_c = bytes_rank + float(total_c)      # compress = srcSize + cSize per frame
         algo_d = float(total_c) + bytes_rank      #              decompress = cSize + dstSize
         wg, lds = enc.last_launch()
-        kernel_c = "zsa_k_compress" if args.level < 4 else "zsa_k_compress_lazy" if args.level > 4 else "zsa_k_compress + zsa_k_compress_lazy"
-        if os.environ.get("ZSA_LDS_TABLE") and args.level <= 2:
-            kernel_c = "zsa_k_compress_lds"
+        # the kernel family of the level at this frame size (clevels.h: ZSTD_fast for levels <= 2, ZSTD_dfast for 3-4, greedy/lazy above)
+        kernel_c = "zsa_k_compress" if args.level < 3 else "zsa_k_compress_dfast" if args.level < 5 else "zsa_k_compress_lazy"
         traffic_c, traffic_d, traffic_src = committed_traffic(N, FS, args.level, kernel_c)
         res = {
             "metric": "GB/s compress & decompress round trip (whole job, uncompressed bytes), %d KiB frames, level %d; ratio" % (FS // 1024, args.level),

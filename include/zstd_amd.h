@@ -111,7 +111,7 @@ size_t zsa_batch_profile(zsa_batch* b, int enable, uint64_t* out, void* stream);
 /* ---------------------------------------------------------------------------------------------------------
  * 4. One entry point that allocates nothing.  No counterpart in the reference: it is for callers that cannot call
  *    hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation.
- *    Decompresses nFrames frames described by a DEVICE array of zsa_frame (device pointers inside), writing one
+ *    Decompresses nFrames frames described by a DEVICE array of zsa_frame records (device pointers inside), writing one
  *    result word per frame (bytes or (uint64)-error, as zsa_batch_device_results) to d_results.  Same kernel as
  *    zsa_decompress_enqueue; its workspace (work counter, per-workgroup literal buffer and parked tables) is a
  *    19 MB array inside the library's code object instead of batch-owned memory, each GPU holding its own copy.

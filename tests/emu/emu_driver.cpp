@@ -77,6 +77,7 @@ static void enc_entry(void* a)
     EncArgs* A = (EncArgs*)a;
     u64 r = (A->P.strat == 1 && !A->cd) ? zsa_encode_frame<2>(A->S, A->ht, A->P, A->src, A->srcSize, A->dst, A->cap, A->W, nullptr, 0)
           : A->P.strat >= 3 ? zsa_encode_frame<1>(A->S, A->ht, A->P, A->src, A->srcSize, A->dst, A->cap, A->W, A->cd, A->dictMode)
+          : (A->P.strat == 2 && !A->cd) ? zsa_encode_frame<3>(A->S, A->ht, A->P, A->src, A->srcSize, A->dst, A->cap, A->W, nullptr, 0)
                             : zsa_encode_frame<0>(A->S, A->ht, A->P, A->src, A->srcSize, A->dst, A->cap, A->W, A->cd, A->dictMode);
     if (wv_lane() == 0) A->result = r;
 }

@@ -443,18 +443,16 @@ def test_capacity_contract(z, oracle):
     assert out.raw[:r] == oracle.compress(p, 1)
 
 
-def test_lds_table_kernel_parity(z, oracle):
-    """The opt-in kernel that keeps the ZSTD_fast match table in LDS (24-bit cells, hoisted 64-position window,
-    zsa_parse.h): byte-identical like the default kernel, including the frames it leaves to the default kernel."""
+def test_level1_chunk_and_general_paths(z, oracle):
+    """The ZSTD_fast kernel has two routes through one frame (zsa_parse.h): the 64-position chunk path with the 4-bit
+    filter in LDS (hashLog <= 13: sources up to 128 KiB at level 1) and the general window evaluation it backs off to
+    (and which larger sources use throughout).  Frames on both sides of that limit, ragged ones, degenerate ones and
+    a multi-block one: byte-identical at levels 1, 2 and -1."""
     from zstd_amd import corpus
     rnd = random.Random(3)
     frames = corpus.frames("log", 131072, 6, 42) + corpus.frames("json", 65536, 6, 1234) + corpus.frames("log", 262144, 2, 43) \
         + corpus.frames("json", 1024, 16, 7) + [b"", b"a", bytes(5000), rnd.randbytes(3000), b"ab" * 5000,
                                                  b"".join(rnd.choice([b"alpha ", b"beta ", b"gamma "]) for _ in range(9000)),
                                                  corpus.frames("log", 600000, 1, 9)[0]]
-    os.environ["ZSA_LDS_TABLE"] = "1"
-    try:
-        for level in (1, 2, -1):
-            _check_compress(z, oracle, frames, level)
-    finally:
-        del os.environ["ZSA_LDS_TABLE"]
+    for level in (1, 2, -1):
+        _check_compress(z, oracle, frames, level)

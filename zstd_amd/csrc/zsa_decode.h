@@ -677,7 +677,6 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                     u32 const total = ofBits + mlBits + llBits + llS + mlS + ofS;
                     u32 ofx, mlx, llx, sl, sm, so;
                     u32 const used = bc + total;
-#ifndef ZSA_DEC_NO32
                     if (used <= 32) {   // the usual case: all six fields lie in the top 32 bits of the window, one bit-field extract each
                         u32 const top = (u32)((W << bc) >> 32);
                         u32 const o1 = ofBits, o2 = o1 + mlBits, o3 = o2 + llBits, o4 = o3 + llS, o5 = o4 + mlS;
@@ -686,7 +685,6 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                         ofx = wv_bfe(top, 32u - o1, ofBits); mlx = wv_bfe(top, 32u - o2, mlBits); llx = wv_bfe(top, 32u - o3, llBits);
                         sl = wv_bfe(top, 32u - o4, llS); sm = wv_bfe(top, 32u - o5, mlS); so = wv_bfe(top, 32u - total, ofS);
                     } else
-#endif
                     if (used <= 64) {
                         u64 X = W << bc;
                         pOff -= used >> 3; bc = used & 7;

@@ -8,14 +8,16 @@
 //   literals             zstd_compress_literals.c:40-236, huf_compress.c:147-1406, hist.c:30-165
 //   sequences            zstd_compress.c:2637-2986, zstd_compress_sequences.c:157-383, fse_compress.c:69-525
 //
-// Mapping onto the wave (v1):
-//   * the hash table of the frame lives in LDS (4 << hashLog bytes, dynamic shared memory);
-//   * the greedy parse is one serial dependency chain (every decision changes the table the next one
-//     reads), so it runs on lane 0 and only records packed (litLength, matchLength, offBase) triples;
-//   * literals are gathered afterwards by all 64 lanes from the recorded triples (wave prefix sums),
-//     histograms use LDS atomics from all lanes, the four Huffman streams are packed by four lanes;
-//   * table construction (Huffman tree, FSE normalisation) and the 3-state FSE sequence bitstream are
-//     serial and run on lane 0.
+// Mapping onto the wave:
+//   * one 64-lane wave per frame; the frame's match table lives in the workgroup's slice of the global scratch
+//     (L2 resident), LDS holds a source ring, a 4-bit filter of the table and a bitmap for shared-cell detection;
+//   * ZSTD_fast without a dictionary parses 64 positions per step (zsa_parse.h: chunk path + general window
+//     evaluation), ZSTD_fast with an attached dictionary likewise (zsa_parse_dict.h), greedy/lazy/lazy2 evaluate the
+//     candidates of one position across lanes (zsa_lazy.h); ZSTD_dfast and the ext-dict corner of ZSTD_fast
+//     still run the reference's loop on lane 0;
+//   * literals are gathered by all 64 lanes from the recorded triples (wave prefix sums), histograms use LDS
+//     atomics from all lanes, the four Huffman streams are packed by four lanes, the FSE sequence bitstream by all;
+//   * table construction (Huffman tree, FSE normalisation) is short and serial on lane 0.
 // Serial sections run under `lane == 0` and publish through LDS; every wv_* call is reached by all lanes.
 #pragma once
 #include "zsa_common.h"
@@ -1568,9 +1570,6 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
             }
             wv_sync();
             ZSA_PROF(S, lane, 1);
-#ifdef ZSA_BISECT_PARSE_ONLY   // diagnostics: instruction counts of the parse alone
-            return 100;
-#endif
             u32 const nbSeq = S->u[EU_nbSeq], lastLL = S->u[EU_lastLL];
             // literal bytes = block bytes not covered by matches
             u32 litSize;
