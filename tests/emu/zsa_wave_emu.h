@@ -95,6 +95,7 @@ ZSA_DEV void wv_stg8(unsigned char* p, unsigned v) { *p = (unsigned char)v; }
 ZSA_DEV unsigned wv_ldg8_now(const unsigned char* p) { return wv_ldg8(p); }
 ZSA_DEV unsigned wv_ldg32_now(const unsigned char* p) { return wv_ldg32(p); }
 ZSA_DEV unsigned long long wv_ldg64_now(const unsigned char* p) { return wv_ldg64(p); }
+template <typename A> ZSA_DEV void wv_join(A&, unsigned&, unsigned&) {}
 ZSA_DEV unsigned long long wv_clock() { return 0; }
 ZSA_DEV unsigned wv_atomic_add_lds(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 ZSA_DEV unsigned wv_atomic_or_lds(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }

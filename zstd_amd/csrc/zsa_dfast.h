@@ -1,236 +1,258 @@
-// zsa_dfast.h -- the ZSTD_dfast parse without a dictionary (zstd_double_fast.c:98-305): levels 3-4, level 2 at <= 256 KB.
+// zsa_dfast.h -- the ZSTD_dfast parse without a dictionary (zstd_double_fast.c:98-305): levels 3-4, level 2 at <= 256 KB,
+// executed by all 64 lanes of the wave.
 //
 // Two tables in the workgroup's global scratch: `hashLong` keyed by 8 bytes (hashLog bits) and `hashSmall` keyed by
-// minMatch bytes (chainLog bits).  Per position the candidates are tried in the reference's order: repcode at ip+1,
-// long match at ip, then -- only if the short table has a match at ip -- long match at ip+1 before settling for the
-// short one.
+// minMatch bytes (chainLog bits).  The reference visits positions one by one (step 1, growing by one every 256 bytes
+// without a match) and per position p: enters p into both tables; checks the repcode at p + 1; checks the long table's
+// candidate for p (8 equal bytes); checks the short table's candidate (4 equal bytes) and, if that one holds, prefers a long
+// match at the NEXT position over it.
 //
-// The chain is walked by one lane (the frames of a launch still run 16 per CU) as a software pipeline,
-// because every table probe is a ~1000-cycle access (tools/microbench/loaded_latency.hip: the tables of the frames in
-// flight total 1.5 GiB).  Three positions are in flight -- p0 being decided, p1, p2:
-//   iteration for p0:   store p0 into both cells
-//                       cells of p1 (requested one iteration ago) arrive; a cell that is the one just stored is patched to p0
-//                       request: candidate bytes and repcode bytes of p1, both cells of p2
-//                       decide p0 with the candidate bytes requested one iteration ago; request the source word of p3
-// The three register sets rotate by renaming (the loop body is written out three times): copying a value that is still in
-// flight would have to wait for it.  The section's state is seeded with wv_vzero() so that it stays in vector registers.
-// What this buys is limited (+10 %) because a search episode of this corpus is only ~3 positions long: filling the
-// pipeline, the match extension and the post-match inserts are ~5 round trips per match that no prefetch distance hides --
-// evaluating all positions of an episode at once (the cooperative window of zsa_parse.h) is the real next step.
-// Included by zsa_encode.h.
+// Here a WINDOW is up to 63 consecutive positions plus one look-ahead position, lane k <-> position ip0 + k:
+//   * every lane reads its 8 source bytes, hashes them twice, reads both cells and then -- in one more round trip -- the
+//     bytes of the long candidate, of the short candidate and of the repcode; lane order == position order and
+//     rep > long > short inside a lane, so the first lane of ONE ballot with any hit is the event the reference stops at;
+//   * the "long match at the next position" of a short hit is the long probe of the next lane, which the window has already
+//     made (the lane after the last position probes the long table only);
+//   * a lane's probes are exact as long as no earlier lane of the window falls into the same cell of the same table; lanes
+//     that share a cell are found with a bitmap pass per table (cell numbers modulo 16384) and the window is cut below the
+//     second-lowest of them; a look-ahead probe that may be stale is simply repeated after the window's stores;
+//   * positions up to the event enter both tables in one store each (distinct cells), then the reference's
+//     complementary positions, then the immediate-repcode loop.
+// Match lengths are counted by all lanes, a byte per lane, forwards and backwards in the same round trip.
+// Included by zsa_encode.h (uses zsa_hash, zsa_packseq from there).
 #pragma once
 
-// Match extension on one lane: forward from (ip + skip, m + skip) (ZSTD_count, :191/:243/:251) and backward from (ip, m)
-// (the "catch up" loops, :193/:245/:253), with all first-round loads -- 16 bytes forward on both sides, 8 bytes backward on
-// both sides -- issued together: one memory round trip decides most matches of this corpus.  Returns the forward length
-// beyond `skip`; ip and m are moved back by the backward length, which is returned in *bwd.
-ZSA_DEV u32 zsa_dfast_extend(const u8*& ip, const u8*& m, u32 skip, const u8* iend, const u8* anchor, const u8* prefixLowest, u32* bwd)
+#ifndef ZSA_DFAST_W0
+#define ZSA_DFAST_W0 8u    // positions in the first window of a search
+#endif
+
+// common length of [ip, iend) and [m, ...), m < ip; uniform arguments, all lanes (ZSTD_count, zstd_compress_internal.h:755-774)
+ZSA_DEV u32 zsa_df_count(const u8* base, u32 ip, u32 m, u32 iend, int lane)
 {
-    const u8* pIn = ip + skip; const u8* pM = m + skip;
-    u32 const maxBack = (u32)((ip - anchor) < (m - prefixLowest) ? (ip - anchor) : (m - prefixLowest));
-    bool const wideBack = maxBack > 0 && (m - prefixLowest) >= 8;     // then ip - 8 and m - 8 are readable
-    bool const wideFwd = pIn + 16 <= iend;
-    u64 a0 = 0, a1 = 0, b0 = 0, b1 = 0, pa = 0, pb = 0;
-    if (wideFwd) { a0 = wv_ldg64(pIn); a1 = wv_ldg64(pIn + 8); b0 = wv_ldg64(pM); b1 = wv_ldg64(pM + 8); }
-    if (wideBack) { pa = wv_ldg64(ip - 8); pb = wv_ldg64(m - 8); }
-    u32 fwd = 0;
-    if (wideFwd) {
-        u64 const d0 = a0 ^ b0, d1 = a1 ^ b1;
-        if (d0) fwd = (u32)__builtin_ctzll(d0) >> 3;
-        else if (d1) fwd = 8 + ((u32)__builtin_ctzll(d1) >> 3);
-        else {   // long match: keep going 16 bytes per round trip
-            fwd = 16;
-            for (;;) {
-                if (pIn + fwd + 16 <= iend) {
-                    u64 const e0 = wv_ldg64(pIn + fwd) ^ wv_ldg64(pM + fwd), e1 = wv_ldg64(pIn + fwd + 8) ^ wv_ldg64(pM + fwd + 8);
-                    if (e0) { fwd += (u32)__builtin_ctzll(e0) >> 3; break; }
-                    if (e1) { fwd += 8 + ((u32)__builtin_ctzll(e1) >> 3); break; }
-                    fwd += 16;
-                } else {
-                    while (pIn + fwd < iend && wv_ldg8(pIn + fwd) == wv_ldg8(pM + fwd)) fwd++;
-                    break;
-                }
-            }
-        }
-    } else {
-        while (pIn + fwd < iend && wv_ldg8(pIn + fwd) == wv_ldg8(pM + fwd)) fwd++;
+    u32 total = 0;
+    for (;;) {
+        u32 const a = ip + total + (u32)lane;
+        bool const same = a < iend && wv_ldg8(base + a) == wv_ldg8(base + m + total + (u32)lane);
+        u64 const stop = wv_ballot(!same);
+        if (stop) return total + (u32)__builtin_ctzll(stop);
+        total += ZSA_WAVE;
     }
-    u32 back = 0;
-    if (wideBack) {
-        u64 const d = pa ^ pb;
-        back = d ? ((u32)__builtin_clzll(d) >> 3) : 8;              // equal bytes counted from ip[-1] downwards
-        if (back > maxBack) back = maxBack;
-        if (back == 8) while (back < maxBack && wv_ldg8(ip - 1 - back) == wv_ldg8(m - 1 - back)) back++;
-    } else {
-        while (back < maxBack && wv_ldg8(ip - 1 - back) == wv_ldg8(m - 1 - back)) back++;
+}
+// forward from (ip + skip, m + skip) and backward from (ip - 1, m - 1) -- the "catch up" loops, :193/:245/:253: ip stays
+// above `anchor`, m above `low` -- with the first round of both directions in one round trip
+ZSA_DEV void zsa_df_extend(const u8* base, u32 ip, u32 m, u32 skip, u32 iend, u32 anchor, u32 low, u32* fwd, u32* bwd, int lane)
+{
+    u32 const room = (ip - anchor) < (m - low) ? (ip - anchor) : (m - low);
+    u32 const a = ip + skip + (u32)lane;
+    bool const fin = a < iend, bin = (u32)lane < room;
+    u32 const f0 = wv_ldg8(base + (fin ? a : ip)), f1 = wv_ldg8(base + (fin ? m + skip + (u32)lane : ip));
+    u32 const b0 = wv_ldg8(base + (bin ? ip - 1 - (u32)lane : ip)), b1 = wv_ldg8(base + (bin ? m - 1 - (u32)lane : ip));
+    u64 const fstop = wv_ballot(!(fin && f0 == f1)), bstop = wv_ballot(!(bin && b0 == b1));
+    *fwd = fstop ? (u32)__builtin_ctzll(fstop) : ZSA_WAVE + zsa_df_count(base, ip + skip + ZSA_WAVE, m + skip + ZSA_WAVE, iend, lane);
+    u32 back = bstop ? (u32)__builtin_ctzll(bstop) : ZSA_WAVE;   // (a lane at or beyond `room` counts as a mismatch: back <= room)
+    if (!bstop) while (back < room) {   // more than 64 bytes backwards: rare
+        u32 const k = back + (u32)lane;
+        bool const same = k < room && wv_ldg8(base + ip - 1 - k) == wv_ldg8(base + m - 1 - k);
+        u64 const stop = wv_ballot(!same);
+        if (stop) { back += (u32)__builtin_ctzll(stop); break; }
+        back += ZSA_WAVE;
     }
-    ip -= back; m -= back;
     *bwd = back;
-    return fwd;
-}
-// ZSTD_count alone (repcode matches have no backward step at this strategy), 16 bytes per round trip
-ZSA_DEV u32 zsa_dfast_count(const u8* pIn, const u8* pMatch, const u8* const pInLimit)
-{
-    const u8* const pStart = pIn;
-    while (pIn + 16 <= pInLimit) {
-        u64 const a0 = wv_ldg64(pIn), a1 = wv_ldg64(pIn + 8), b0 = wv_ldg64(pMatch), b1 = wv_ldg64(pMatch + 8);
-        u64 const d0 = a0 ^ b0, d1 = a1 ^ b1;
-        if (d0) return (u32)(pIn - pStart) + ((u32)__builtin_ctzll(d0) >> 3);
-        if (d1) return (u32)(pIn - pStart) + 8 + ((u32)__builtin_ctzll(d1) >> 3);
-        pIn += 16; pMatch += 16;
-    }
-    while (pIn < pInLimit && wv_ldg8(pIn) == wv_ldg8(pMatch)) { pIn++; pMatch++; }
-    return (u32)(pIn - pStart);
 }
 
-// `base`: window base (index i <-> base + i).  Appends packed sequences to seqOut, returns their number; rep[] and
-// *lastLL are updated.  Runs on one lane.
-ZSA_DEV u32 zsa_parse_dfast(u32* hashLong, u32* hashSmall, const ZsaEncParams& P, const u8* base, u32 dictLimit,
-                            const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL)
+// Parses one block.  base: window base (index i <-> base + i).  bmL, bmS: LDS, 512 words each, all zero (left all zero).
+// rep: LDS, [0] and [1] in and out, [2] receives the last literal run.  Returns the number of sequences appended to seqOut.
+// All arguments and the result are wave-uniform.  (A function of its own: its loop gets its own register allocation.)
+ZSA_DEVFN u32 zsa_parse_dfast_wave(u32* hashLong, u32* hashSmall, u32 hBitsL, u32 hBitsS, u32 mls, u32 wlog, const u8* base, u32 dictLimit,
+                                   const u8* src, u32 srcSize, u32* rep, u64* seqOut, u32* bmL, u32* bmS)
 {
-    u32 const hBitsL = P.hlog, hBitsS = P.clog, mls = P.mml;
-    const u8* const istart = src;
-    u32 const endIndex = (u32)(istart - base) + srcSize;
-    u32 const maxDistance = 1u << P.wlog;
+    int const lane = wv_lane();
+    hashLong = (u32*)wv_uniform64((u64)hashLong); hashSmall = (u32*)wv_uniform64((u64)hashSmall);
+    hBitsL = wv_uniform(hBitsL); hBitsS = wv_uniform(hBitsS); mls = wv_uniform(mls); wlog = wv_uniform(wlog);
+    base = (const u8*)wv_uniform64((u64)base); dictLimit = wv_uniform(dictLimit);
+    src = (const u8*)wv_uniform64((u64)src); srcSize = wv_uniform(srcSize); seqOut = (u64*)wv_uniform64((u64)seqOut);
+    u32 const istart = (u32)(src - base), iend = istart + srcSize, ilimit = iend - 8;
+    u32 const maxDistance = 1u << wlog;
     // ZSTD_getLowestPrefixIndex (zstd_compress_internal.h:1307-1318), no loaded dictionary
-    u32 const prefixLowestIndex = (endIndex - dictLimit > maxDistance) ? endIndex - maxDistance : dictLimit;
-    const u8* const prefixLowest = base + prefixLowestIndex;
-    const u8* const iend = istart + srcSize;
-    const u8* const ilimit = iend - 8;
-    const u8* anchor = istart;
-    const u8* ip = istart + wv_vzero();   // per-lane state: loads stay in flight until they are used (zsa_wave_hip.h)
-    u32 off1 = rep[0], off2 = rep[1], saved1 = 0, saved2 = 0, nbSeq = 0;
-
-    ip += (ip == prefixLowest);
-    {   u32 const current = (u32)(ip - base);
-        u32 const windowLow = (current - dictLimit > maxDistance) ? current - maxDistance : dictLimit;
-        u32 const maxRep = current - windowLow;
+    u32 const prefixLowest = (iend - dictLimit > maxDistance) ? iend - maxDistance : dictLimit;
+    u32 ip0 = istart, anchor = istart;
+    u32 off1 = wv_uniform(rep[0]), off2 = wv_uniform(rep[1]), saved1 = 0, saved2 = 0, nbSeq = 0;
+    ip0 += (ip0 == prefixLowest);                                     // :132
+    {   u32 const windowLow = (ip0 - dictLimit > maxDistance) ? ip0 - maxDistance : dictLimit;   // :133-139
+        u32 const maxRep = ip0 - windowLow;
         if (off2 > maxRep) { saved2 = off2; off2 = 0; }
         if (off1 > maxRep) { saved1 = off1; off1 = 0; }
     }
-    // candidate bytes: indices at or below the prefix start are never dereferenced by the reference; here they are
-    // redirected to the block start (any readable address) and the result is ignored
-#define ZSA_CAND(idx) ((idx) > prefixLowestIndex ? base + (idx) : istart)
-    u64 pre0 = 0, pre1 = 0, pre2 = 0; bool havePre = false;
-    for (;;) {   // one stored match per iteration (:156)
-        u32 step = 1;
-        const u8* nextStep = ip + 256;     // 1 << kSearchStrength (:125)
-        const u8* ip1 = ip + 1;
-        u32 curr = 0, offset = 0, mLength = 0, hl1 = 0, skip = 0;
-        const u8* mPtr = base;
-        int outcome = 0;                   // 0 block exhausted, 1 repcode stored, 2 match at (ip, offset, mLength)
-        if (ip1 > ilimit) break;
-        // ---- three positions are in flight (p0 being decided, p1, p2); their state lives in three register sets that
-        // rotate by renaming (the loop body is written out three times), because a register-to-register copy of a
-        // value still in flight would have to wait for it.
-        const u8* Pp[3]; u64 Vw[3]; u32 HL[3], HS[3], IL[3], IS[3], MS[3], RR[3]; u64 ML[3];
-        Pp[0] = ip; Pp[1] = ip1; Pp[2] = ip1 + 1;   // the step is 1 for the first 256 bytes
-        if (havePre) { Vw[0] = pre0; Vw[1] = pre1; Vw[2] = pre2; havePre = false; }   // requested with the post-match loads
-        else { Vw[0] = wv_ldg64(Pp[0]); Vw[1] = wv_ldg64(Pp[1]); Vw[2] = wv_ldg64(Pp[2] <= ilimit ? Pp[2] : Pp[1]); }
-        HL[0] = zsa_hash(Vw[0], hBitsL, 8); HS[0] = zsa_hash(Vw[0], hBitsS, mls);
-        HL[1] = zsa_hash(Vw[1], hBitsL, 8); HS[1] = zsa_hash(Vw[1], hBitsS, mls);
-        IL[0] = wv_ldg_cell(hashLong + HL[0]); IS[0] = wv_ldg_cell(hashSmall + HS[0]);
-        IL[1] = wv_ldg_cell(hashLong + HL[1]); IS[1] = wv_ldg_cell(hashSmall + HS[1]);   // before the store of p0: patched below
-        RR[0] = wv_ldg32(ip + 1 - off1);
-        ML[0] = wv_ldg64(ZSA_CAND(IL[0]));
-        MS[0] = wv_ldg32(ZSA_CAND(IS[0]));
-        HL[2] = HS[2] = IL[2] = IS[2] = MS[2] = RR[1] = RR[2] = MS[1] = 0; ML[1] = ML[2] = 0;
-        // one position (:170-223): a = the position decided now, b and c the next two
-#define ZSA_DFAST_POS(a, b, c)                                                                                              \
-        {   curr = (u32)(Pp[a] - base);                                                                                     \
-            wv_stg_cell(hashLong + HL[a], curr); wv_stg_cell(hashSmall + HS[a], curr);                                      \
-            if (HL[b] == HL[a]) IL[b] = curr;            /* the cells of p1 were read before this store */                   \
-            if (HS[b] == HS[a]) IS[b] = curr;                                                                               \
-            /* requests: candidates and repcode bytes of p1, cells of p2 */                                                 \
-            ML[b] = wv_ldg64(ZSA_CAND(IL[b]));                                                                              \
-            MS[b] = wv_ldg32(ZSA_CAND(IS[b]));                                                                              \
-            RR[b] = wv_ldg32(Pp[b] + 1 - off1);                                                                             \
-            u32 const stepNext = step + (Pp[b] >= nextStep);             /* :208-213: the step from p1 to p2 */             \
-            const u8* const nextStep1 = nextStep + ((Pp[b] >= nextStep) ? 256 : 0);                                         \
-            u32 const stepNext2 = stepNext + (Pp[c] >= nextStep1);       /* the step from p2 to p3 */                       \
-            const u8* const Pd = Pp[c] + stepNext2;                                                                         \
-            bool const has2 = Pp[c] <= ilimit;                                                                              \
-            HL[c] = zsa_hash(Vw[c], hBitsL, 8); HS[c] = zsa_hash(Vw[c], hBitsS, mls);                                       \
-            IL[c] = wv_ldg_cell(hashLong + (has2 ? HL[c] : HL[b]));                                                         \
-            IS[c] = wv_ldg_cell(hashSmall + (has2 ? HS[c] : HS[b]));                                                        \
-            /* decide p0 */                                                                                                 \
-            if ((off1 > 0) & (RR[a] == (u32)(Vw[a] >> 8))) {   /* :179-184 repcode at ip+1 */                               \
-                ip = Pp[a]; ip1 = Pp[b]; hl1 = HL[b];                                                                       \
-                outcome = 1;                                                                                                \
-                break;                                                                                                      \
-            }                                                                                                               \
-            if (IL[a] > prefixLowestIndex && ML[a] == Vw[a]) {   /* :188-196 long match at ip */                            \
-                ip = Pp[a]; ip1 = Pp[b]; hl1 = HL[b];                                                                       \
-                mPtr = base + IL[a]; skip = 8;                                                                              \
-                outcome = 2;                                                                                                \
-                break;                                                                                                      \
-            }                                                                                                               \
-            if (IS[a] > prefixLowestIndex && MS[a] == (u32)Vw[a]) {   /* :201-206 -> :237-253 */                            \
-                ip = Pp[a]; ip1 = Pp[b]; hl1 = HL[b];                                                                       \
-                if (IL[b] > prefixLowestIndex && ML[b] == Vw[b]) { ip = ip1; mPtr = base + IL[b]; skip = 8; }               \
-                else { mPtr = base + IS[a]; skip = 4; }                                                                     \
-                outcome = 2;                                                                                                \
-                break;                                                                                                      \
-            }                                                                                                               \
-            /* no match here: p3 takes the register set of p0 */                                                            \
-            nextStep = nextStep1; step = stepNext;                                                                          \
-            Pp[a] = Pd; Vw[a] = wv_ldg64(Pd <= ilimit ? Pd : Pp[b]);                                                        \
-            if (!(Pp[c] <= ilimit)) break;                   /* `while (ip1 <= ilimit)` for the new p1 */                   \
+    u32 step = 1, nextStep = ip0 + 256;                               // :157-158, kStepIncr = 1 << kSearchStrength
+    // Every position of a window costs two scattered cell reads and three candidate reads, and the tables of the frames in
+    // flight are far larger than the caches: a window is only as wide as the search is likely to last.  It starts narrow
+    // after a match and doubles while nothing is found.
+    u32 width = ZSA_DFAST_W0;
+    // pv: the 8 source bytes at pvAt + lane for lanes below pvN (where readable): requested along with the last match's inserts,
+    // or left over from the previous window of the same search
+    u64 pv = 0; u32 pvAt = 0, pvN = 0;
+    if (srcSize >= 9 && ip0 + 1 <= ilimit)
+    for (;;) {   // one window per iteration
+        // positions: consecutive while the step is 1, up to and including the first one at or beyond nextStep (whose own
+        // step is 2); beyond that one position per window.  Then one look-ahead position: where the last one steps to.
+        u32 nAct = 1;
+        if (step == 1) { u32 const a = nextStep - ip0 + 1; nAct = a < width ? a : width; }
+        u32 const lastAct = ip0 + nAct - 1;
+        u32 const lastStep = step == 1 ? ((nAct > 1 && lastAct >= nextStep) ? 2u : 1u) : step;
+        u32 const cur = (u32)lane < nAct ? ip0 + (u32)lane : lastAct + lastStep;
+        u32 const myStep = (u32)lane == nAct - 1 ? lastStep : 1u;
+        bool const valid = (u32)lane < nAct && cur + myStep <= ilimit;          // the reference reaches it (:164, :223)
+        u32 nEff = (u32)__builtin_popcountll(wv_ballot(valid));                 // (a prefix of the lanes)
+        if (nEff == 0) break;
+        bool ends = nEff < nAct;
+        bool const probe = (u32)lane <= nEff;                                   // lane nEff: look-ahead, long table only
+        bool const both = (u32)lane < nEff;
+        u64 v = 0; u32 hL = 0, hS = 0, iL = 0, iS = 0;
+        if (pvAt != ip0) { pv = wv_ldg64(base + (ip0 + (u32)lane <= ilimit ? ip0 + (u32)lane : ip0)); pvAt = ip0; pvN = ZSA_WAVE; }
+        if (probe) {
+            v = (cur == ip0 + (u32)lane && (u32)lane < pvN) ? pv : wv_ldg64(base + cur);
+            hL = zsa_hash(v, hBitsL, 8);
+            hS = zsa_hash(v, hBitsS, mls);
+            iL = wv_ldg_cell(hashLong + hL);
         }
-        for (;;) {
-            ZSA_DFAST_POS(0, 1, 2)
-            ZSA_DFAST_POS(1, 2, 0)
-            ZSA_DFAST_POS(2, 0, 1)
+        if (both) iS = wv_ldg_cell(hashSmall + hS);
+        u64 sharedL;
+        {   // lanes that share a cell with another lane of the window, per table: cut the window below the second-lowest
+            u32* const dwL = bmL + ((hL >> 5) & 511u); u32 const bitL = 1u << (hL & 31u);
+            u32* const dwS = bmS + ((hS >> 5) & 511u); u32 const bitS = 1u << (hS & 31u);
+            bool lateL = false, lateS = false;
+            if (probe) lateL = (wv_atomic_or_lds(dwL, bitL) & bitL) != 0;
+            if (both) lateS = (wv_atomic_or_lds(dwS, bitS) & bitS) != 0;
+            wv_lds_fence();
+            if (lateL) (void)wv_atomic_and_lds(dwL, ~bitL);
+            if (lateS) (void)wv_atomic_and_lds(dwS, ~bitS);
+            wv_lds_fence();
+            bool const shL = probe && (lateL || !(*dwL & bitL));
+            bool const shS = both && (lateS || !(*dwS & bitS));
+            wv_lds_fence();
+            if (probe) *dwL = 0;
+            if (both) *dwS = 0;
+            wv_lds_fence();
+            sharedL = wv_ballot(shL);
+            u64 const sharedS = wv_ballot(shS);
+            u64 const GL2 = sharedL & (sharedL - 1), GS2 = sharedS & (sharedS - 1);
+            u32 w = ZSA_WAVE;
+            if (GL2) w = (u32)__builtin_ctzll(GL2);
+            if (GS2) { u32 const ws = (u32)__builtin_ctzll(GS2); w = ws < w ? ws : w; }
+            if (w < nEff) { nEff = w; ends = false; }                           // (w >= 1)
         }
-#undef ZSA_DFAST_POS
-        // the match is measured once, outside the position loop
-        if (outcome == 1) {
-            mLength = zsa_dfast_count(ip + 5, ip + 5 - off1, iend) + 4;
-            ip++;
-            seqOut[nbSeq++] = zsa_packseq((u32)(ip - anchor), mLength - ZSA_MINMATCH, 1);
-        } else if (outcome == 2) {
-            u32 bw;
-            offset = (u32)(ip - mPtr);
-            mLength = zsa_dfast_extend(ip, mPtr, skip, iend, anchor, prefixLowest, &bw) + skip + bw;
+        bool const mine = (u32)lane < nEff;
+        // candidate bytes of all three checks in one round trip (a lane without a candidate reads its own position)
+        bool const hasL = probe && iL > prefixLowest, hasS = mine && iS > prefixLowest;
+        u64 cL = wv_ldg64(base + (hasL ? iL : istart));
+        u32 cS = wv_ldg32(base + (hasS ? iS : istart));
+        u32 cR = wv_ldg32(base + (mine ? cur + 1 - off1 : istart));
+        wv_join(cL, cS, cR);
+        bool const longHit = hasL && cL == v;
+        u32 kind = 0;   // 1: repcode at cur + 1 (:179), 2: long match at cur (:188), 3: short match at cur (:201)
+        if (mine) {
+            if (off1 > 0 && cR == (u32)(v >> 8)) kind = 1;
+            else if (longHit) kind = 2;
+            else if (hasS && cS == (u32)v) kind = 3;
         }
-        if (outcome == 0) break;
-        if (outcome == 2) {   // _match_found (:257-272)
-            off2 = off1; off1 = offset;
-            if (step < 4) wv_stg_cell(hashLong + hl1, (u32)(ip1 - base));
-            seqOut[nbSeq++] = zsa_packseq((u32)(ip - anchor), mLength - ZSA_MINMATCH, offset + 3);
-        }
-        ip += mLength;   // _match_stored (:274-303)
-        anchor = ip;
-        if (ip <= ilimit) {
-            u32 const indexToInsert = curr + 2;
-            u64 const va = wv_ldg64(base + indexToInsert), vb = wv_ldg64(ip - 2);
-            u64 vi = wv_ldg64(ip);
-            u32 ri = wv_ldg32(ip - off2);
-            // the source words the next search starts with, in the same round trip
-            pre1 = wv_ldg64(ip + 1 <= ilimit ? ip + 1 : ip); pre2 = wv_ldg64(ip + 2 <= ilimit ? ip + 2 : ip);
-            wv_stg_cell(hashLong + zsa_hash(va, hBitsL, 8), indexToInsert);
-            wv_stg_cell(hashLong + zsa_hash(vb, hBitsL, 8), (u32)(ip - 2 - base));
-            wv_stg_cell(hashSmall + zsa_hash(va, hBitsS, mls), indexToInsert);
-            wv_stg_cell(hashSmall + zsa_hash(vb >> 8, hBitsS, mls), (u32)(ip - 1 - base));   // bytes at ip-1 (mls <= 7)
-            while ((off2 > 0) & ((u32)vi == ri)) {   // immediate repcode (:290-302); ip <= ilimit holds
-                u32 const rLength = zsa_dfast_count(ip + 4, ip + 4 - off2, iend) + 4;
-                { u32 const t = off2; off2 = off1; off1 = t; }
-                wv_stg_cell(hashSmall + zsa_hash(vi, hBitsS, mls), (u32)(ip - base));
-                wv_stg_cell(hashLong + zsa_hash(vi, hBitsL, 8), (u32)(ip - base));
-                seqOut[nbSeq++] = zsa_packseq(0, rLength - ZSA_MINMATCH, 1);
-                ip += rLength;
-                anchor = ip;
-                if (ip > ilimit) break;
-                vi = wv_ldg64(ip); ri = wv_ldg32(ip - off2);
-                pre1 = wv_ldg64(ip + 1 <= ilimit ? ip + 1 : ip); pre2 = wv_ldg64(ip + 2 <= ilimit ? ip + 2 : ip);
+        u64 const found = wv_ballot(kind != 0);
+        u32 const nIns = found ? (u32)__builtin_ctzll(found) + 1 : nEff;        // positions that enter the tables (:174)
+        if ((u32)lane < nIns) { wv_stg_cell(hashLong + hL, cur); wv_stg_cell(hashSmall + hS, cur); }   // (distinct cells: the window was cut)
+        wv_lds_fence();
+        if (!found) {
+            if (ends) break;
+            // the step after the last position of the window (:208-223)
+            u32 const last = ip0 + nEff - 1;
+            u32 const s = step + ((nEff > 1 && last >= nextStep) ? 1u : 0u);    // the step that position was reached with
+            if (s != step) { step = s; nextStep += 256; }
+            {   u32 const d = last + step - ip0;       // the source bytes this window fetched beyond its end serve the next one
+                if (d < pvN) {
+                    pv = (u64)wv_shfl((u32)pv, lane + (int)d) | ((u64)wv_shfl((u32)(pv >> 32), lane + (int)d) << 32);
+                    pvN -= d; pvAt = ip0 + d;
+                }
             }
-            if (ip + 1 <= ilimit) { pre0 = vi; havePre = true; }
+            ip0 = last + step;
+            if (ip0 >= nextStep) { step++; nextStep += 256; }
+            width = width * 2 < ZSA_WAVE - 1 ? width * 2 : ZSA_WAVE - 1;
+            continue;
         }
+        int const e = __builtin_ctzll(found);
+        u32 const eKind = wv_readlane(kind, e), curE = ip0 + (u32)e;
+        u32 const eStep = (u32)e == nAct - 1 ? lastStep : 1u;                   // `step` as the reference holds it at this position
+        u32 const ip1 = wv_readlane(cur, e + 1), hl1 = wv_readlane(hL, e + 1);
+        u32 start, mLength, offBase;
+        if (eKind == 1) {
+            start = curE + 1;
+            mLength = zsa_df_count(base, start + 4, start + 4 - off1, iend, lane) + 4;
+            offBase = 1;
+        } else {
+            u32 ipM = curE, m, skip;
+            if (eKind == 2) { m = wv_readlane(iL, e); skip = 8; }
+            else {   // _search_next_long (:237-253): a long match at ip1 beats the short one at ip
+                u32 iL1; bool hit1;
+                if (!((sharedL >> (e + 1)) & 1)) { iL1 = wv_readlane(iL, e + 1); hit1 = wv_readlane(longHit ? 1u : 0u, e + 1) != 0; }
+                else {   // that lane's probe may predate a store of this window: read the cell again
+                    iL1 = wv_uniform(wv_ldg_cell(hashLong + hl1));
+                    u64 const v1 = (u64)wv_readlane((u32)v, e + 1) | ((u64)wv_readlane((u32)(v >> 32), e + 1) << 32);
+                    hit1 = iL1 > prefixLowest && wv_uniform64(wv_ldg64(base + (iL1 > prefixLowest ? iL1 : istart))) == v1;
+                }
+                if (hit1) { ipM = ip1; m = iL1; skip = 8; } else { m = wv_readlane(iS, e); skip = 4; }
+            }
+            u32 fwd, bwd;
+            zsa_df_extend(base, ipM, m, skip, iend, anchor, prefixLowest, &fwd, &bwd, lane);
+            start = ipM - bwd;
+            mLength = skip + fwd + bwd;
+            off2 = off1; off1 = ipM - m;                                        // _match_found (:257-259)
+            if (eStep < 4 && lane == 0) wv_stg_cell(hashLong + hl1, ip1);       // :261-266
+            wv_lds_fence();
+            offBase = off1 + 3;
+        }
+        if (lane == 0) wv_stg64(seqOut + nbSeq, zsa_packseq(start - anchor, mLength - ZSA_MINMATCH, offBase));
+        nbSeq++;
+        ip0 = start + mLength;                                                  // _match_stored (:274-303)
+        anchor = ip0;
+        if (ip0 <= ilimit) {
+            // complementary insertion (:279-287): curr + 2 and ip - 2 into the long table, curr + 2 and ip - 1 into the short
+            // one; lane 2 fetches what the immediate-repcode check needs in the same round trip
+            u32 const pp = lane == 0 ? curE + 2 : (lane == 1 ? ip0 - 2 : ip0);
+            u64 w = 0; u32 r2 = 0, r3 = 0;
+            if (lane < 3) w = wv_ldg64(base + pp);
+            if (lane == 2) r2 = wv_ldg32(base + ip0 - off2);
+            pv = wv_ldg64(base + (ip0 + (u32)lane <= ilimit ? ip0 + (u32)lane : ip0)); pvAt = ip0; pvN = ZSA_WAVE;   // the next window's source bytes
+            wv_join(pv, r2, r3);
+            u32 const hl = zsa_hash(w, hBitsL, 8);
+            u32 const hs = zsa_hash(lane == 1 ? w >> 8 : w, hBitsS, mls);       // lane 1: the bytes at ip - 1 (mls <= 7)
+            if (lane == 0) { wv_stg_cell(hashLong + hl, pp); wv_stg_cell(hashSmall + hs, pp); }
+            wv_lds_fence();
+            if (lane == 1) { wv_stg_cell(hashLong + hl, pp); wv_stg_cell(hashSmall + hs, pp + 1); }
+            wv_lds_fence();
+            u32 vi = wv_readlane((u32)w, 2), ri = wv_readlane(r2, 2);
+            u32 hli = wv_readlane(hl, 2), hsi = wv_readlane(hs, 2);
+            while ((off2 > 0) & (vi == ri)) {   // immediate repcode (:290-302); ip0 <= ilimit holds
+                u32 const rLength = zsa_df_count(base, ip0 + 4, ip0 + 4 - off2, iend, lane) + 4;
+                { u32 const t = off2; off2 = off1; off1 = t; }
+                if (lane == 0) {
+                    wv_stg_cell(hashSmall + hsi, ip0); wv_stg_cell(hashLong + hli, ip0);
+                    wv_stg64(seqOut + nbSeq, zsa_packseq(0, rLength - ZSA_MINMATCH, 1));
+                }
+                wv_lds_fence();
+                nbSeq++;
+                ip0 += rLength;
+                anchor = ip0;
+                if (ip0 > ilimit) break;
+                pv = wv_ldg64(base + (ip0 + (u32)lane <= ilimit ? ip0 + (u32)lane : ip0)); pvAt = ip0; pvN = ZSA_WAVE;
+                ri = wv_ldg32(base + ip0 - off2);
+                wv_join(pv, ri, r3);
+                u64 const wi = (u64)wv_readlane((u32)pv, 0) | ((u64)wv_readlane((u32)(pv >> 32), 0) << 32);
+                vi = (u32)wi; ri = wv_uniform(ri);
+                hli = zsa_hash(wi, hBitsL, 8); hsi = zsa_hash(wi, hBitsS, mls);
+            }
+        }
+        step = 1; nextStep = ip0 + 256;                                         // :157-158 a new search
+        width = ZSA_DFAST_W0;
+        if (ip0 + 1 > ilimit) break;                                            // :164
     }
-#undef ZSA_CAND
-    saved2 = ((saved1 != 0) && (off1 != 0)) ? saved1 : saved2;   // _cleanup (:225-235)
-    rep[0] = off1 ? off1 : saved1;
-    rep[1] = off2 ? off2 : saved2;
-    *lastLL = (u32)(iend - anchor);
-    return nbSeq;
+    saved2 = ((saved1 != 0) && (off1 != 0)) ? saved1 : saved2;                  // _cleanup (:225-235)
+    if (lane == 0) { rep[0] = off1 ? off1 : saved1; rep[1] = off2 ? off2 : saved2; rep[2] = iend - anchor; }
+    return wv_uniform(nbSeq);
 }

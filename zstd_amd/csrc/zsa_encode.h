@@ -1532,11 +1532,17 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
                 u32 lastLL = 0, nbSeq;
                 if (FAMILY == 1) {   // greedy / lazy / lazy2 (never with a dictionary here): wave-uniform, zsa_lazy.h
                     nbSeq = zsa_parse_lazy(LZ, Wn.dictLimit, ip, blockSize, P.strat - 3, rep, W.seq, &lastLL, lane);
-                } else if (FAMILY == 3) {   // ZSTD_dfast (never with a dictionary here): serial for now, zsa_dfast.h
-                    nbSeq = 0;
-                    if (lane == 0) nbSeq = zsa_parse_dfast(hashTable, hashTable + (1u << P.hlog), P, Wn.base, Wn.dictLimit, ip, blockSize, rep, W.seq, &lastLL);
-                    nbSeq = wv_shfl(nbSeq, 0); lastLL = wv_shfl(lastLL, 0);
-                    rep[0] = wv_shfl(rep[0], 0); rep[1] = wv_shfl(rep[1], 0);
+                } else if (FAMILY == 3) {   // ZSTD_dfast (never with a dictionary here): wave-level, zsa_dfast.h
+                    // its two cell bitmaps lie in `filt`, which overlays table-construction scratch and the last block's FSE tables
+                    // (never used again below ZSTD_lazy), not the Huffman table that is carried from block to block
+                    for (u32 i = (u32)lane; i < sizeof(S->filt) / 4; i += ZSA_WAVE) S->filt[i] = 0;
+                    u32* const io = &S->u[EU_s0];   // offsets in and out, last literal run out
+                    if (lane == 0) { io[0] = rep[0]; io[1] = rep[1]; io[2] = 0; }
+                    wv_sync();
+                    nbSeq = wv_uniform(zsa_parse_dfast_wave(hashTable, hashTable + (1u << P.hlog), P.hlog, P.clog, P.mml, P.wlog, Wn.base, Wn.dictLimit,
+                                                            ip, blockSize, io, W.seq, S->filt, S->filt + 512));
+                    wv_sync();
+                    rep[0] = io[0]; rep[1] = io[1]; lastLL = io[2];
                 } else {   // ZSTD_fast without a dictionary segment: the wave parser (zsa_parse.h)
                     // its stage takes the whole LDS: the previous block's Huffman table waits in global scratch meanwhile
                     u32* const park = (u32*)W.tmp;

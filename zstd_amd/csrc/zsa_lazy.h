@@ -21,6 +21,22 @@
 // Included by zsa_encode.h.
 #pragma once
 
+// ZSTD_count by one lane's loads (every lane of the uniform chain makes the same ones), 16 bytes per round trip
+ZSA_DEV u32 zsa_lz_count(const u8* pIn, const u8* pMatch, const u8* const pInLimit)
+{
+    const u8* const pStart = pIn;
+    while (pIn + 16 <= pInLimit) {
+        u64 const a0 = wv_ldg64(pIn), a1 = wv_ldg64(pIn + 8), b0 = wv_ldg64(pMatch), b1 = wv_ldg64(pMatch + 8);
+        u64 const d0 = a0 ^ b0, d1 = a1 ^ b1;
+        if (d0) return (u32)(pIn - pStart) + ((u32)__builtin_ctzll(d0) >> 3);
+        if (d1) return (u32)(pIn - pStart) + 8 + ((u32)__builtin_ctzll(d1) >> 3);
+        pIn += 16; pMatch += 16;
+    }
+    while (pIn < pInLimit && wv_ldg8(pIn) == wv_ldg8(pMatch)) { pIn++; pMatch++; }
+    return (u32)(pIn - pStart);
+}
+
+
 // zstd_compress.c:1916-1927: the hash salt of a fresh context, ZSTD_advanceHashSalt on hashSalt = hashSaltEntropy = 0
 constexpr u64 zsa_bitmix_c(u64 val, u64 len)
 {
@@ -94,7 +110,7 @@ ZSA_DEV void zsa_lazy_evaluate(const ZsaLazyCtx& C, const u8* ip, const u8* iLim
 {
     if (nCand == 0) return;
     bool const mine = (u32)lane < nCand;
-    u32 const len = mine ? zsa_dfast_count(ip, C.base + myIndex, iLimit) : 0u;
+    u32 const len = mine ? zsa_lz_count(ip, C.base + myIndex, iLimit) : 0u;
     u32 best = *ml, which = ZSA_WAVE;
     for (u32 k = 0; k < nCand; k++) { u32 const l = wv_readlane(len, (int)k); if (l > best) { best = l; which = k; } }   // first maximum
     if (which < ZSA_WAVE) {
@@ -325,7 +341,7 @@ ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcS
         u64 vip = zsa_win_get64(W, ip, iend);
         // :1578-1582 repcode at ip+1
         if ((offset_1 > 0) && (zsa_win_get32(R, ip + 1 - offset_1, iend) == (u32)(vip >> 8))) {
-            matchLength = zsa_dfast_count(ip + 1 + 4, ip + 1 + 4 - offset_1, iend) + 4;
+            matchLength = zsa_lz_count(ip + 1 + 4, ip + 1 + 4 - offset_1, iend) + 4;
             if (depth == 0) storeNow = true;
         }
         if (!storeNow) {
@@ -344,7 +360,7 @@ ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcS
                 ip++;
                 vip = zsa_win_get64(W, ip, iend);
                 if ((offBase) && ((offset_1 > 0) && ((u32)vip == zsa_win_get32(R, ip - offset_1, iend)))) {
-                    u32 const mlRep = zsa_dfast_count(ip + 4, ip + 4 - offset_1, iend) + 4;
+                    u32 const mlRep = zsa_lz_count(ip + 4, ip + 4 - offset_1, iend) + 4;
                     s32 const gain2 = (s32)(mlRep * 3);
                     s32 const gain1 = (s32)(matchLength * 3 - ZSA_HB(offBase) + 1);
                     if ((mlRep >= 4) && (gain2 > gain1)) { matchLength = mlRep; offBase = 1; start = ip; }
@@ -359,7 +375,7 @@ ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcS
                     ip++;
                     vip = zsa_win_get64(W, ip, iend);
                     if ((offBase) && ((offset_1 > 0) && ((u32)vip == zsa_win_get32(R, ip - offset_1, iend)))) {
-                        u32 const mlRep = zsa_dfast_count(ip + 4, ip + 4 - offset_1, iend) + 4;
+                        u32 const mlRep = zsa_lz_count(ip + 4, ip + 4 - offset_1, iend) + 4;
                         s32 const gain2 = (s32)(mlRep * 4);
                         s32 const gain1 = (s32)(matchLength * 4 - ZSA_HB(offBase) + 1);
                         if ((mlRep >= 4) && (gain2 > gain1)) { matchLength = mlRep; offBase = 1; start = ip; }
@@ -398,7 +414,7 @@ ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcS
         C.lazySkipping = 0;   // :1705-1711
         // :1735-1745 immediate repcode
         while ((ZSA_UPTO_LIMIT(ip) & (offset_2 > 0)) && (wv_ldg32(ip) == wv_ldg32(ip - offset_2))) {
-            matchLength = zsa_dfast_count(ip + 4, ip + 4 - offset_2, iend) + 4;
+            matchLength = zsa_lz_count(ip + 4, ip + 4 - offset_2, iend) + 4;
             { u32 const t = offset_2; offset_2 = offset_1; offset_1 = t; }
             if (lane == 0) seqOut[nbSeq] = zsa_packseq(0, matchLength - ZSA_MINMATCH, 1);
             nbSeq++;

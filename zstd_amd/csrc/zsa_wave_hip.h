@@ -61,6 +61,9 @@ ZSA_DEV void wv_stg8(unsigned char* p, unsigned v) { *(__attribute__((address_sp
 ZSA_DEV unsigned wv_ldg8_now(const unsigned char* p) { unsigned v = wv_ldg8(p); asm volatile("" : "+v"(v)); return v; }
 ZSA_DEV unsigned wv_ldg32_now(const unsigned char* p) { unsigned v = wv_ldg32(p); asm volatile("" : "+v"(v)); return v; }
 ZSA_DEV unsigned long long wv_ldg64_now(const unsigned char* p) { unsigned long long v = wv_ldg64(p); asm volatile("" : "+v"(v)); return v; }
+// Loads issued together, consumed together: pins the point where all of the given loaded values must have arrived, so the
+// compiler cannot sink each load into the branch that uses it (which would turn one memory round trip into several).
+template <typename A> ZSA_DEV void wv_join(A& a, unsigned& b, unsigned& c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); }
 ZSA_DEV unsigned long long wv_clock() { return (unsigned long long)clock64(); }
 ZSA_DEV unsigned wv_atomic_add_lds(unsigned* p, unsigned v) { return atomicAdd(p, v); }
 ZSA_DEV unsigned wv_atomic_or_lds(unsigned* p, unsigned v) { return atomicOr(p, v); }
