@@ -140,30 +140,9 @@ ZSA_DEV u32 zsa_hash(u64 v, u32 hBits, u32 mls)
     case 8: return (u32)((v * 0xCF1BBCDCB7A56463ULL) >> (64 - hBits));
     }
 }
-ZSA_DEV u32 zsa_count(const u8* pIn, const u8* pMatch, const u8* const pInLimit)
-{   // ZSTD_count: common-prefix length, capped at pInLimit
-    const u8* const pStart = pIn;
-    while (pIn + 8 <= pInLimit) {
-        u64 const diff = zsa_ld64(pMatch) ^ zsa_ld64(pIn);
-        if (diff) return (u32)(pIn - pStart) + ((u32)__builtin_ctzll(diff) >> 3);
-        pIn += 8; pMatch += 8;
-    }
-    while (pIn < pInLimit && *pIn == *pMatch) { pIn++; pMatch++; }
-    return (u32)(pIn - pStart);
-}
-
 #include "zsa_parse.h"
 #include "zsa_dfast.h"
 #include "zsa_lazy.h"
-
-// zstd_compress_internal.h:780-793 ZSTD_count_2segments
-ZSA_DEV u32 zsa_count_2segments(const u8* ip, const u8* match, const u8* iEnd, const u8* mEnd, const u8* iStart)
-{
-    const u8* const vEnd = (ip + (mEnd - match) < iEnd) ? ip + (mEnd - match) : iEnd;
-    u32 const matchLength = zsa_count(ip, match, vEnd);
-    if (match + matchLength != mEnd) return matchLength;
-    return matchLength + zsa_count(ip + matchLength, iStart, iEnd);
-}
 
 // window of one frame (zstd_compress_internal.h ZSTD_window_t + the match-state fields the fast parsers read)
 struct ZsaWindow {
@@ -174,146 +153,6 @@ struct ZsaWindow {
 };
 
 #include "zsa_parse_dict.h"   // parse with an attached dictionary (zstd_fast.c:459-656), wave-level
-
-// ------------------------------------------------------------------ parse, dictionary as extDict (zstd_fast.c:685-936), serial
-// Returns 0xFFFFFFFF when the extDict has been invalidated for this block (zstd_fast.c:737-738): the caller
-// then runs the plain parser.
-ZSA_DEV u32 zsa_parse_fast_ext(u32* hashTable, const ZsaEncParams& P, const ZsaWindow& Wn,
-                               const u8* src, u32 srcSize, u32 rep[3], u64* seqOut, u32* lastLL)
-{
-    u32 const hlog = P.hlog, mls = P.mml;
-    u32 const stepSize = P.tlen + !P.tlen + 1;
-    const u8* const base = Wn.base;
-    const u8* const dictBase = Wn.dictBase;
-    const u8* const istart = src;
-    const u8* anchor = istart;
-    u32 const endIndex = (u32)(istart - base) + srcSize;
-    u32 lowLimit;
-    {   // ZSTD_getLowestMatchIndex (zstd_compress_internal.h:1290-1302)
-        u32 const maxDistance = 1u << P.wlog, lowestValid = Wn.lowLimit;
-        u32 const withinWindow = (endIndex - lowestValid > maxDistance) ? endIndex - maxDistance : lowestValid;
-        lowLimit = Wn.loadedDictEnd != 0 ? lowestValid : withinWindow;
-    }
-    u32 const dictStartIndex = lowLimit;
-    const u8* const dictStart = dictBase + dictStartIndex;
-    u32 const dictLimit = Wn.dictLimit;
-    u32 const prefixStartIndex = dictLimit < lowLimit ? lowLimit : dictLimit;
-    const u8* const prefixStart = base + prefixStartIndex;
-    const u8* const dictEnd = dictBase + prefixStartIndex;
-    const u8* const iend = istart + srcSize;
-    const u8* const ilimit = iend - 8;
-    u32 offset_1 = rep[0], offset_2 = rep[1], offsetSaved1 = 0, offsetSaved2 = 0;
-    const u8* ip0 = istart;
-    u32 nbSeq = 0;
-
-    if (prefixStartIndex == dictStartIndex) return 0xFFFFFFFFu;
-    {   u32 const curr = (u32)(ip0 - base);
-        u32 const maxRep = curr - dictStartIndex;
-        if (offset_2 >= maxRep) { offsetSaved2 = offset_2; offset_2 = 0; }
-        if (offset_1 >= maxRep) { offsetSaved1 = offset_1; offset_1 = 0; }
-    }
-    for (;;) {
-        u32 step = stepSize;
-        const u8* nextStep = ip0 + 128;
-        const u8* ip1 = ip0 + 1;
-        const u8* ip2 = ip0 + step;
-        const u8* ip3 = ip2 + 1;
-        u32 hash0, hash1, idx, current0 = 0, offcode = 0, mLength = 0;
-        const u8* idxBase;
-        const u8* match0 = base;
-        const u8* matchEnd = iend;
-        int found = 0;
-        if (ip3 >= ilimit) break;
-        hash0 = zsa_hash(zsa_ld64(ip0), hlog, mls);
-        hash1 = zsa_hash(zsa_ld64(ip1), hlog, mls);
-        idx = hashTable[hash0];
-        idxBase = idx < prefixStartIndex ? dictBase : base;
-        do {
-            {   u32 const current2 = (u32)(ip2 - base);
-                u32 const repIndex = current2 - offset_1;
-                const u8* const repBase = repIndex < prefixStartIndex ? dictBase : base;
-                u32 rval;
-                if (((u32)(prefixStartIndex - repIndex) >= 4) & (offset_1 > 0)) rval = zsa_ld32(repBase + repIndex);
-                else rval = zsa_ld32(ip2) ^ 1;
-                current0 = (u32)(ip0 - base);
-                hashTable[hash0] = current0;
-                if (zsa_ld32(ip2) == rval) {
-                    ip0 = ip2;
-                    match0 = repBase + repIndex;
-                    matchEnd = repIndex < prefixStartIndex ? dictEnd : iend;
-                    mLength = ip0[-1] == match0[-1];
-                    ip0 -= mLength; match0 -= mLength;
-                    offcode = 1;
-                    mLength += 4;
-                    found = 1;
-                    break;
-                }
-            }
-            {   u32 const mval = idx >= dictStartIndex ? zsa_ld32(idxBase + idx) : zsa_ld32(ip0) ^ 1;
-                if (zsa_ld32(ip0) == mval) { found = 2; break; }
-            }
-            idx = hashTable[hash1];
-            idxBase = idx < prefixStartIndex ? dictBase : base;
-            hash0 = hash1;
-            hash1 = zsa_hash(zsa_ld64(ip2), hlog, mls);
-            ip0 = ip1; ip1 = ip2; ip2 = ip3;
-            current0 = (u32)(ip0 - base);
-            hashTable[hash0] = current0;
-            {   u32 const mval = idx >= dictStartIndex ? zsa_ld32(idxBase + idx) : zsa_ld32(ip0) ^ 1;
-                if (zsa_ld32(ip0) == mval) { found = 2; break; }
-            }
-            idx = hashTable[hash1];
-            idxBase = idx < prefixStartIndex ? dictBase : base;
-            hash0 = hash1;
-            hash1 = zsa_hash(zsa_ld64(ip2), hlog, mls);
-            ip0 = ip1; ip1 = ip2;
-            ip2 = ip0 + step;
-            ip3 = ip1 + step;
-            if (ip2 >= nextStep) { step++; nextStep += 128; }
-        } while (ip3 < ilimit);
-        if (!found) break;
-        if (found == 2) {
-            u32 const offset = current0 - idx;
-            const u8* const lowMatchPtr = idx < prefixStartIndex ? dictStart : prefixStart;
-            matchEnd = idx < prefixStartIndex ? dictEnd : iend;
-            match0 = idxBase + idx;
-            offset_2 = offset_1;
-            offset_1 = offset;
-            offcode = offset + 3;
-            mLength = 4;
-            while (((ip0 > anchor) & (match0 > lowMatchPtr)) && (ip0[-1] == match0[-1])) { ip0--; match0--; mLength++; }
-        }
-        mLength += zsa_count_2segments(ip0 + mLength, match0 + mLength, iend, matchEnd, prefixStart);
-        seqOut[nbSeq++] = zsa_packseq((u32)(ip0 - anchor), mLength - ZSA_MINMATCH, offcode);
-        ip0 += mLength;
-        anchor = ip0;
-        if (ip1 < ip0) hashTable[hash1] = (u32)(ip1 - base);
-        if (ip0 <= ilimit) {
-            hashTable[zsa_hash(zsa_ld64(base + current0 + 2), hlog, mls)] = current0 + 2;
-            hashTable[zsa_hash(zsa_ld64(ip0 - 2), hlog, mls)] = (u32)(ip0 - 2 - base);
-            while (ip0 <= ilimit) {
-                u32 const repIndex2 = (u32)(ip0 - base) - offset_2;
-                const u8* const repMatch2 = repIndex2 < prefixStartIndex ? dictBase + repIndex2 : base + repIndex2;
-                if ((((u32)((prefixStartIndex - 1) - repIndex2) >= 3) & (offset_2 > 0)) && (zsa_ld32(repMatch2) == zsa_ld32(ip0))) {
-                    const u8* const repEnd2 = repIndex2 < prefixStartIndex ? dictEnd : iend;
-                    u32 const repLength2 = zsa_count_2segments(ip0 + 4, repMatch2 + 4, iend, repEnd2, prefixStart) + 4;
-                    { u32 const t = offset_2; offset_2 = offset_1; offset_1 = t; }
-                    seqOut[nbSeq++] = zsa_packseq(0, repLength2 - ZSA_MINMATCH, 1);
-                    hashTable[zsa_hash(zsa_ld64(ip0), hlog, mls)] = (u32)(ip0 - base);
-                    ip0 += repLength2;
-                    anchor = ip0;
-                    continue;
-                }
-                break;
-            }
-        }
-    }
-    offsetSaved2 = ((offsetSaved1 != 0) && (offset_1 != 0)) ? offsetSaved1 : offsetSaved2;
-    rep[0] = offset_1 ? offset_1 : offsetSaved1;
-    rep[1] = offset_2 ? offset_2 : offsetSaved2;
-    *lastLL = (u32)(iend - anchor);
-    return nbSeq;
-}
 
 // ------------------------------------------------------------------ FSE (fse_compress.c), serial helpers
 ZSA_DEV u32 zsa_fse_minTableLog(u32 srcSize, u32 maxSV)
@@ -1518,12 +1357,18 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
                     S->nextRep[0] = io[0]; S->nextRep[1] = io[1];
                     S->u[EU_nbSeq] = nbSeq; S->u[EU_lastLL] = io[2];
                 }
-            } else if (dictParse && lane == 0) {   // dictionary as extDict: serial (payloads above 8 KiB with a dictionary)
-                u32 rep[3] = { S->prevRep[0], S->prevRep[1], S->prevRep[2] };
-                u32 lastLL = 0;
-                u32 const nbSeq = zsa_parse_fast_ext(hashTable, P, Wn, ip, blockSize, rep, W.seq, &lastLL);   // 0xFFFFFFFF: extDict invalidated
-                S->nextRep[0] = rep[0]; S->nextRep[1] = rep[1]; S->nextRep[2] = rep[2];
-                S->u[EU_nbSeq] = nbSeq; S->u[EU_lastLL] = lastLL;
+            } else if (dictParse) {   // dictionary as an external segment (payloads above 8 KiB with a dictionary): wave-level too
+                for (u32 i = (u32)lane; i < sizeof(S->dupBits) / 4; i += ZSA_WAVE) S->dupBits[i] = 0;
+                u32* const io = &S->u[EU_s0];
+                if (lane == 0) { io[0] = S->prevRep[0]; io[1] = S->prevRep[1]; io[2] = 0; }
+                wv_sync();
+                u32 const nbSeq = wv_uniform(zsa_parse_ext_wave(hashTable, P.hlog, P.mml, P.tlen, P.wlog, Wn.base, Wn.dictBase, Wn.dictLimit, Wn.lowLimit,
+                                                                Wn.loadedDictEnd, ip, blockSize, io, W.seq, S->dupBits));   // 0xFFFFFFFF: segment invalidated
+                wv_sync();
+                if (lane == 0) {
+                    S->nextRep[0] = io[0]; S->nextRep[1] = io[1]; S->nextRep[2] = S->prevRep[2];
+                    S->u[EU_nbSeq] = nbSeq; S->u[EU_lastLL] = io[2];
+                }
             }
             wv_sync();
             if (!dictParse || S->u[EU_nbSeq] == 0xFFFFFFFFu) {
