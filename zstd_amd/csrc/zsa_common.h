@@ -127,6 +127,62 @@ ZSA_DEV u32 zsa_OF_base(u32 c) { return c == 0 ? 0 : (c == 1 ? 1 : (1u << c) - 3
 
 ZSA_DEV u32 zsa_highbit32(u32 v) { return 31u - (u32)__builtin_clz(v); }
 
+// ---- FSE table layout by the whole wave (shared by the encoder's and the decoder's table builders) --------------------------
+// Both FSE_buildCTable_wksp (fse_compress.c:69-215) and ZSTD_buildFSETable_body (zstd_decompress_block.c:455-573) lay the
+// symbols out the same way: low-probability symbols (norm == -1) take the top cells in symbol order; every other symbol s
+// takes norm[s] of the remaining cells, which are visited in the order 0, step, 2 step, ... (mod tableSize); and each cell
+// then needs the RANK of its position among the cells of the same symbol, in position order (it selects the state the cell
+// stands for).  The reference does this with two serial loops over the table.  Here:
+//   * lane s owns symbol s (at most 53 sequence codes, 13 Huffman weights): a wave prefix sum of the frequencies gives the
+//     first visit of every symbol;
+//   * the visits are taken 64 at a time: the j-th visit lands on cell (j * step) mod tableSize, a ballot drops the visits that
+//     land in the low-probability zone, and the lane finds the symbol of its visit by a 6-step search in the prefix sums;
+//   * the cells are then taken 64 at a time in position order: six ballots over the bits of the symbol tell a lane which
+//     other lanes hold the same symbol, the ones below it plus a per-symbol running count give its rank.
+// emit(cell, symbol, rank) is called once per cell by the lane that owns it.  norm, and the three scratch arrays, are LDS.
+struct ZsaSpreadScratch { u16* first; u16* seen; u8* sym; };   // first: 64 entries, seen: 64 entries, sym: tableSize entries
+template <class EMIT>
+ZSA_DEV void zsa_fse_spread_wave(const ZsaSpreadScratch& X, const s16* norm, u32 maxSV, u32 tableLog, int lane, EMIT emit)
+{
+    u32 const tableSize = 1u << tableLog, tableMask = tableSize - 1, step = ZSA_FSE_TABLESTEP(tableSize);
+    u64 const below = ((u64)1 << lane) - 1;
+    int const n = (u32)lane <= maxSV ? (int)norm[lane] : 0;
+    u32 const freq = n > 0 ? (u32)n : 0;
+    u32 const firstVisit = wv_scan_incl(freq) - freq;
+    u64 const lowMask = wv_ballot(n == -1);
+    u32 const high = tableSize - 1 - (u32)__builtin_popcountll(lowMask);        // highThreshold
+    X.first[lane] = (u16)firstVisit;
+    X.seen[lane] = 0;
+    if (n == -1) X.sym[tableSize - 1 - (u32)__builtin_popcountll(lowMask & below)] = (u8)lane;
+    wv_lds_fence();
+    u32 taken = 0;
+    for (u32 j0 = 0; j0 < tableSize; j0 += ZSA_WAVE) {
+        u32 const j = j0 + (u32)lane, cell = (j * step) & tableMask;
+        bool const lands = j < tableSize && cell <= high;
+        u64 const lm = wv_ballot(lands);
+        u32 const k = taken + (u32)__builtin_popcountll(lm & below);             // the lane's visit is the k-th that counts
+        taken += (u32)__builtin_popcountll(lm);
+        if (lands) {   // the last symbol whose first visit is at or before k
+            u32 s = 0;
+            for (u32 b = 32; b; b >>= 1) { u32 const t = s + b; if (t <= maxSV && X.first[t] <= k) s = t; }
+            X.sym[cell] = (u8)s;
+        }
+    }
+    wv_lds_fence();
+    for (u32 c0 = 0; c0 < tableSize; c0 += ZSA_WAVE) {
+        u32 const cell = c0 + (u32)lane;
+        bool const on = cell < tableSize;
+        u32 const s = on ? X.sym[cell] : 0;
+        u64 same = wv_ballot(on);
+        for (u32 b = 0; b < 6; b++) { u64 const bb = wv_ballot((s >> b) & 1); same &= ((s >> b) & 1) ? bb : ~bb; }
+        u32 const rank = on ? X.seen[s] + (u32)__builtin_popcountll(same & below) : 0;
+        wv_lds_fence();
+        if (on && (same >> lane) == 1) X.seen[s] += (u16)__builtin_popcountll(same);   // the highest lane of the group
+        wv_lds_fence();
+        if (on) emit(cell, s, rank);
+    }
+}
+
 // ---- unaligned little-endian memory access ----
 ZSA_DEV u32 zsa_ld16(const u8* p) { u16 v; __builtin_memcpy(&v, p, 2); return v; }
 ZSA_DEV u32 zsa_ld24(const u8* p) { return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16); }

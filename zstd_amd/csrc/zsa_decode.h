@@ -354,62 +354,63 @@ ZSA_DEV u32 zsa_huf_decodeStream(const ZsaDecShared* S, u8* p, u8* const pEnd, c
 }
 
 // ------------------------------------------------------------------ sequence tables
-// zstd_decompress_block.c:455-573 ZSTD_buildFSETable_body, serial (one lane). kind: 0 LL, 1 OF, 2 ML
+// zstd_decompress_block.c:455-573 ZSTD_buildFSETable_body by the whole wave: the layout comes from zsa_fse_spread_wave
+// (zsa_common.h); a cell's state number is its symbol's cell count plus the cell's rank.  kind: 0 LL, 1 OF, 2 ML.  norm: LDS.
 ZSA_DEV u32 zsa_seq_base(int kind, u32 s) { return kind == 0 ? zsa_LL_base(s) : (kind == 1 ? zsa_OF_base(s) : zsa_ML_base(s)); }
 ZSA_DEV u32 zsa_seq_bits(int kind, u32 s) { return kind == 0 ? zsa_LL_bits(s) : (kind == 1 ? s : zsa_ML_bits(s)); }
-ZSA_DEV void zsa_buildSeqTable(ZsaDecShared* S, ZsaSeqCell* cell, const s16* norm, u32 maxSV, int kind, u32 tableLog)
+ZSA_DEV void zsa_buildSeqTable(ZsaDecShared* S, ZsaSeqCell* cell, const s16* norm, u32 maxSV, int kind, u32 tableLog, int lane)
 {
-    u32 const tableSize = 1u << tableLog, tableMask = tableSize - 1, step = ZSA_FSE_TABLESTEP(tableSize);
-    u32 highThreshold = tableSize - 1, position = 0;
-    for (u32 s = 0; s <= maxSV; s++) {
-        if (norm[s] == -1) { cell[highThreshold--] = s; S->symbolNext[s] = 1; }
-        else S->symbolNext[s] = (u16)norm[s];
-    }
-    for (u32 s = 0; s <= maxSV; s++) {
-        for (int i = 0; i < norm[s]; i++) {
-            cell[position] = s;
-            position = (position + step) & tableMask;
-            while (position > highThreshold) position = (position + step) & tableMask;
-        }
-    }
-    for (u32 u = 0; u < tableSize; u++) {
-        u32 const symbol = (u32)cell[u];
-        u32 const nextState = S->symbolNext[symbol]++;
+    u32 const tableSize = 1u << tableLog;
+    ZsaSpreadScratch X; X.first = S->symbolNext; X.seen = S->symbolNext + 64; X.sym = (u8*)S->symStart;
+    zsa_fse_spread_wave(X, norm, maxSV, tableLog, lane, [&](u32 u, u32 symbol, u32 rank) {
+        int const n = norm[symbol];
+        u32 const nextState = (n == -1 ? 1u : (u32)n) + rank;
         u32 const nbBits = tableLog - zsa_highbit32(nextState);
         cell[u] = zsa_seqcell(zsa_seq_base(kind, symbol), ((nextState << nbBits) - tableSize) & 0xFFFF, zsa_seq_bits(kind, symbol), nbBits);
-    }
+    });
+    wv_lds_fence();
 }
-// zstd_decompress_block.c:617-663 ZSTD_buildSeqTable, serial.  Returns bytes read; sets *err.
+// zstd_decompress_block.c:617-663 ZSTD_buildSeqTable: the table description is read by lane 0, the table is built by all lanes.
+// Returns bytes read (wave-uniform); raises S->err.
 ZSA_DEV u32 zsa_buildSeqTableFromHeader(ZsaDecShared* S, ZsaSeqCell* cell, u32* logPtr, int type, int kind,
-                                        const u8* src, u32 srcSize, int flagRepeatTable, u32* err)
+                                        const u8* src, u32 srcSize, int flagRepeatTable, int lane)
 {
     u32 const max = kind == 0 ? ZSA_MaxLL : (kind == 1 ? ZSA_MaxOff : ZSA_MaxML);
     u32 const maxLog = kind == 1 ? ZSA_OffFSELog : 9;
     switch (type) {
     case zsa_set_rle:
-        if (!srcSize) { *err = ZSA_srcSize_wrong; return 0; }
-        if (src[0] > max) { *err = ZSA_corruption_detected; return 0; }
-        cell[0] = zsa_seqcell(zsa_seq_base(kind, src[0]), 0, zsa_seq_bits(kind, src[0]), 0);
-        *logPtr = 0;
+        if (lane == 0) {
+            if (!srcSize) S->err = ZSA_srcSize_wrong;
+            else if (src[0] > max) S->err = ZSA_corruption_detected;
+            else { cell[0] = zsa_seqcell(zsa_seq_base(kind, src[0]), 0, zsa_seq_bits(kind, src[0]), 0); *logPtr = 0; }
+        }
+        wv_lds_fence();
         return 1;
     case zsa_set_basic: {
         u32 const dmax = kind == 0 ? ZSA_MaxLL : (kind == 1 ? ZSA_DefaultMaxOff : ZSA_MaxML);
         u32 const dlog = kind == 1 ? ZSA_OF_DEFAULTNORMLOG : 6;
-        for (u32 s = 0; s <= dmax; s++)
-            S->norm[s] = (s16)(kind == 0 ? zsa_LL_defaultNorm(s) : (kind == 1 ? zsa_OF_defaultNorm(s) : zsa_ML_defaultNorm(s)));
-        zsa_buildSeqTable(S, cell, S->norm, dmax, kind, dlog);
-        *logPtr = dlog;
+        if ((u32)lane <= dmax)
+            S->norm[lane] = (s16)(kind == 0 ? zsa_LL_defaultNorm((u32)lane) : (kind == 1 ? zsa_OF_defaultNorm((u32)lane) : zsa_ML_defaultNorm((u32)lane)));
+        if (lane == 0) *logPtr = dlog;
+        wv_lds_fence();
+        zsa_buildSeqTable(S, cell, S->norm, dmax, kind, dlog, lane);
         return 0; }
     case zsa_set_repeat:
-        if (!flagRepeatTable) { *err = ZSA_corruption_detected; return 0; }
+        if (!flagRepeatTable && lane == 0) S->err = ZSA_corruption_detected;
+        wv_lds_fence();
         return 0;
     default: {
-        u32 tableLog = 0, maxSV = max;
-        u32 const h = zsa_readNCount(S->norm, &maxSV, &tableLog, src, srcSize, err);
-        if (*err) { *err = ZSA_corruption_detected; return 0; }
-        if (tableLog > maxLog) { *err = ZSA_corruption_detected; return 0; }
-        zsa_buildSeqTable(S, cell, S->norm, maxSV, kind, tableLog);
-        *logPtr = tableLog;
+        u32 tableLog = 0, maxSV = max, h = 0;
+        if (lane == 0) {
+            u32 err = 0;
+            h = zsa_readNCount(S->norm, &maxSV, &tableLog, src, srcSize, &err);
+            if (err || tableLog > maxLog) { S->err = ZSA_corruption_detected; tableLog = 0; }
+            else *logPtr = tableLog;
+        }
+        wv_lds_fence();
+        tableLog = wv_shfl(tableLog, 0); maxSV = wv_shfl(maxSV, 0); h = wv_shfl(h, 0);
+        if (tableLog == 0) return 0;                  // (a valid description has tableLog >= 5)
+        zsa_buildSeqTable(S, cell, S->norm, maxSV, kind, tableLog, lane);
         return h; }
     }
 }
@@ -569,14 +570,15 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
     wv_sync();   // literal bytes written by some lanes are read by all below
     ZSA_PROF(S, lane, 2);
 
-    // ---- sequences header + tables (zstd_decompress_block.c:665-742), lane 0
+    // ---- sequences header (zstd_decompress_block.c:665-742): lane 0 reads the count and the three modes, then the three tables
+    // are built one after the other by all lanes
     u32 const seqOff = S->u[ZU_seqOff];
     if (lane == 0) {
         const u8* const istart = src + seqOff;
         u32 const n = srcSize - seqOff;
         const u8* ip = istart;
         const u8* const iend = istart + n;
-        u32 err = 0, nbSeq = 0;
+        u32 err = 0, nbSeq = 0, haveModes = 0;
         if (n < 1) err = ZSA_srcSize_wrong;
         else {
             nbSeq = *ip++;
@@ -588,21 +590,34 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                 }
                 if (!err && ip + 1 > iend) err = ZSA_srcSize_wrong;
                 if (!err) {
-                    int const LLtype = *ip >> 6, OFtype = (*ip >> 4) & 3, MLtype = (*ip >> 2) & 3;
-                    S->u[ZU_streams] = (u32)LLtype; S->u[ZU_hufOff] = (u32)OFtype; S->u[ZU_hufCSize] = (u32)MLtype;
+                    S->u[ZU_streams] = (u32)(*ip >> 6); S->u[ZU_hufOff] = (u32)((*ip >> 4) & 3); S->u[ZU_hufCSize] = (u32)((*ip >> 2) & 3);
                     ip++;
-                    ip += zsa_buildSeqTableFromHeader(S, S->ll, &S->llLog, LLtype, 0, ip, (u32)(iend - ip), C.fseEntropy, &err);
-                    if (!err) ip += zsa_buildSeqTableFromHeader(S, S->of, &S->ofLog, OFtype, 1, ip, (u32)(iend - ip), C.fseEntropy, &err);
-                    if (!err) ip += zsa_buildSeqTableFromHeader(S, S->ml, &S->mlLog, MLtype, 2, ip, (u32)(iend - ip), C.fseEntropy, &err);
-                    if (err) err = ZSA_corruption_detected;
+                    haveModes = 1;
                 }
             }
         }
-        if (!err && nbSeq > 0 && cap == 0) err = ZSA_dstSize_tooSmall;
         S->err = err;
         S->u[ZU_nbSeq] = nbSeq;
-        S->u[ZU_seqSize] = (u32)(iend - ip);
+        S->u[ZU_batchN] = haveModes;
         S->u[ZU_tmp] = (u32)(ip - src);
+    }
+    wv_sync();
+    if (S->err) return 0;
+    if (S->u[ZU_batchN]) {
+        u32 at = S->u[ZU_tmp];
+        int const types[3] = { (int)S->u[ZU_streams], (int)S->u[ZU_hufOff], (int)S->u[ZU_hufCSize] };
+        for (int k = 0; k < 3; k++) {   // LL, OF, ML
+            ZsaSeqCell* const cell = k == 0 ? S->ll : (k == 1 ? S->of : S->ml);
+            u32* const logPtr = k == 0 ? &S->llLog : (k == 1 ? &S->ofLog : &S->mlLog);
+            at += zsa_buildSeqTableFromHeader(S, cell, logPtr, types[k], k, src + at, srcSize - at, C.fseEntropy, lane);
+            wv_sync();
+            if (S->err) { if (lane == 0) S->err = ZSA_corruption_detected; wv_sync(); return 0; }
+        }
+        if (lane == 0) S->u[ZU_tmp] = at;
+    }
+    if (lane == 0) {
+        if (S->u[ZU_nbSeq] > 0 && cap == 0) S->err = ZSA_dstSize_tooSmall;
+        S->u[ZU_seqSize] = srcSize - S->u[ZU_tmp];
     }
     wv_sync();
     if (S->err) return 0;

@@ -36,21 +36,17 @@ ZSA_DEV u32 zsa_digest_ddict(ZsaDecShared* S, const u8* dict, u32 dictSize, ZsaD
     for (u32 i = (u32)lane; i < (1u << S->hufLog); i += ZSA_WAVE) T->huf[i] = S->huf[i];
     wv_sync();   // the sequence tables are built over the same LDS bytes
     // OF, ML, LL in this order (zstd_decompress.c:1455-1498)
+    for (int k = 0; k < 3; k++) {   // each description read by lane 0, each table built by all lanes
+        int const kind = k == 0 ? 1 : (k == 1 ? 2 : 0);
+        ZsaSeqCell* const cell = kind == 0 ? S->ll : (kind == 1 ? S->of : S->ml);
+        u32* const logPtr = kind == 0 ? &S->llLog : (kind == 1 ? &S->ofLog : &S->mlLog);
+        pos += zsa_buildSeqTableFromHeader(S, cell, logPtr, zsa_set_compressed, kind, dict + pos, dictSize - pos, 0, lane);
+        wv_sync();
+        if (S->err) return ZSA_dictionary_corrupted;
+    }
     if (lane == 0) {
         u32 err = 0, p = pos;
-        for (int k = 0; k < 3 && !err; k++) {
-            int const kind = k == 0 ? 1 : (k == 1 ? 2 : 0);
-            u32 maxSV = kind == 0 ? ZSA_MaxLL : (kind == 1 ? ZSA_MaxOff : ZSA_MaxML), tableLog = 0;
-            u32 const maxLog = kind == 1 ? ZSA_OffFSELog : 9;
-            u32 const h = zsa_readNCount(S->norm, &maxSV, &tableLog, dict + p, dictSize - p, &err);
-            if (err) break;
-            if (tableLog > maxLog) { err = ZSA_dictionary_corrupted; break; }
-            ZsaSeqCell* const cell = kind == 0 ? S->ll : (kind == 1 ? S->of : S->ml);
-            zsa_buildSeqTable(S, cell, S->norm, maxSV, kind, tableLog);
-            if (kind == 0) S->llLog = tableLog; else if (kind == 1) S->ofLog = tableLog; else S->mlLog = tableLog;
-            p += h;
-        }
-        if (!err && p + 12 > dictSize) err = ZSA_dictionary_corrupted;
+        if (p + 12 > dictSize) err = ZSA_dictionary_corrupted;
         if (!err) {
             u32 const dictContentSize = dictSize - (p + 12);
             for (int i = 0; i < 3; i++) {

@@ -341,6 +341,74 @@ ZSA_DEV void zsa_fse_buildCTable(ZsaEncShared* S, u16* nextState, s32* dfs, u32*
         }
     }
 }
+// The same normalisation by the whole wave, lane s <-> symbol s (sequence codes: at most 53 symbols).  count, norm: LDS.
+// Every symbol's share is independent of the others (fse_compress.c:487-508); what couples them -- the cells left over, the
+// first symbol with the largest share, which absorbs them -- is a wave sum, a wave maximum and a ballot.  The rare
+// second-chance distribution (FSE_normalizeM2) stays a serial routine on lane 0.  Returns 0 ok, 1 error; wave-uniform.
+ZSA_DEV u32 zsa_fse_normalizeCount_wave(s16* norm, u32 tableLog, const u32* count, u32 total, u32 maxSV, u32 useLowProb, int lane)
+{
+    if (tableLog < ZSA_FSE_MIN_TABLELOG || tableLog > ZSA_FSE_MAX_TABLELOG) return 1;
+    if (tableLog < zsa_fse_minTableLog(total, maxSV)) return 1;
+    bool const mine = (u32)lane <= maxSV;
+    u32 const c = mine ? count[lane] : 0;
+    if (wv_ballot(mine && c == total)) return 0;                 // one symbol only: the caller has chosen RLE (:488)
+    int const lowProbCount = useLowProb ? -1 : 1;
+    u64 const scale = 62 - tableLog, step = ((u64)1 << 62) / total, vStep = (u64)1 << (scale - 20);
+    u32 const lowThreshold = total >> tableLog;
+    int share = 0; u32 cells = 0; bool regular = false;
+    if (c != 0) {
+        if (c <= lowThreshold) { share = lowProbCount; cells = 1; }
+        else {
+            u32 p = (u32)(((u64)c * step) >> scale);
+            if (p < 8) {   // round up when the remainder beats the threshold of this small share (:494-497)
+                u32 const rtb = p == 0 ? 0u : (p == 1 ? 473195u : (p == 2 ? 504333u : (p == 3 ? 520860u : (p == 4 ? 550000u : (p == 5 ? 700000u : (p == 6 ? 750000u : 830000u))))));
+                p += ((u64)c * step) - ((u64)p << scale) > vStep * rtb;
+            }
+            share = (int)(s16)p; cells = p; regular = true;
+        }
+    }
+    if (mine) norm[lane] = (s16)share;
+    int const still = (int)(1u << tableLog) - (int)wv_reduce_add(cells);
+    u32 const top = wv_reduce_max(regular && share > 0 ? (u32)share : 0u);
+    u64 const tm = wv_ballot(regular && share > 0 && (u32)share == top);
+    u32 const largest = tm ? (u32)__builtin_ctzll(tm) : 0u;
+    wv_lds_fence();
+    int const atLargest = norm[largest];
+    wv_lds_fence();
+    if (-still >= (atLargest >> 1)) {
+        u32 r = 0;
+        if (lane == 0) r = zsa_fse_normalizeM2(norm, tableLog, count, total, maxSV, (s16)lowProbCount);
+        wv_lds_fence();
+        return wv_shfl(r, 0);
+    }
+    if ((u32)lane == largest) norm[largest] = (s16)(atLargest + still);
+    wv_lds_fence();
+    return 0;
+}
+// FSE_buildCTable_wksp (fse_compress.c:69-215) by the whole wave: symbol s's transform and first state from a wave prefix sum
+// of the cell counts, the state table from zsa_fse_spread_wave (zsa_common.h).  norm: LDS; nextState/dfs/dnb: LDS or global.
+ZSA_DEV void zsa_fse_buildCTable_wave(ZsaEncShared* S, u16* nextState, s32* dfs, u32* dnb, const s16* norm, u32 maxSV, u32 tableLog, int lane)
+{
+    u32 const tableSize = 1u << tableLog;
+    int const nc = (u32)lane <= maxSV ? (int)norm[lane] : 0;
+    u32 const cells = nc == -1 ? 1u : (u32)nc;
+    u32 const before = wv_scan_incl(cells) - cells;              // cells of the symbols below this one
+    u16* const firstState = S->cumul + 128;
+    firstState[lane] = (u16)before;
+    if ((u32)lane <= maxSV) {   // symbol transform (:178-201)
+        if (nc == 0) { dnb[lane] = ((tableLog + 1) << 16) - tableSize; dfs[lane] = 0; }
+        else if (nc == -1 || nc == 1) { dnb[lane] = (tableLog << 16) - tableSize; dfs[lane] = (s32)(before - 1); }
+        else {
+            u32 const maxBitsOut = tableLog - zsa_highbit32((u32)nc - 1);
+            dnb[lane] = (maxBitsOut << 16) - ((u32)nc << maxBitsOut);
+            dfs[lane] = (s32)(before - (u32)nc);
+        }
+    }
+    ZsaSpreadScratch X; X.first = S->cumul; X.seen = S->cumul + 64; X.sym = S->tableSymbol;
+    zsa_fse_spread_wave(X, norm, maxSV, tableLog, lane,
+                        [&](u32 cell, u32 sy, u32 rank) { nextState[firstState[sy] + rank] = (u16)(tableSize + cell); });
+    wv_lds_fence();
+}
 // FSE encoder state (fse.h:437-476)
 struct ZsaFseCState { u32 value; const u16* next; const s32* dfs; const u32* dnb; u32 stateLog; };
 ZSA_DEV void zsa_fse_initCState2(ZsaFseCState& st, const u16* next, const s32* dfs, const u32* dnb, u32 tableLog, u32 symbol)
@@ -874,12 +942,14 @@ ZSA_DEV u32 zsa_invProbLog256(u32 x)
     return t[x];
 }
 #define ZSA_COST_ERROR 0xFFFFFFFFu   // ERROR(GENERIC) as a cost: above every real one
-// zstd_compress_sequences.c:157-236 ZSTD_selectEncodingType; serial.  Below ZSTD_lazy: threshold rules (:180-205).  From
-// ZSTD_lazy on: cost estimates (:206-232) -- basic = cross entropy against the default distribution (:140-155), repeat =
-// price under the previous block's table `prevCT` (:105-133 with fse.h:494-509; NULL when there is none), compressed =
-// table description (:71-79, written to `wksp` just to be measured) + entropy bound (:85-99).
+// zstd_compress_sequences.c:157-236 ZSTD_selectEncodingType, by the whole wave (lane s <-> code s; count: LDS; every argument and
+// the result wave-uniform, *repeatMode a per-lane copy of a uniform value).  Below ZSTD_lazy: threshold rules (:180-205).  From
+// ZSTD_lazy on: cost estimates (:206-232), each a sum over the codes and so a wave sum -- basic = cross entropy against the
+// default distribution (:140-155), repeat = price under the previous block's table `prevCT` (:105-133 with fse.h:494-509;
+// NULL when there is none), compressed = table description (:71-79, written to `wksp` just to be measured) + entropy
+// bound (:85-99).
 ZSA_DEV u32 zsa_selectEncodingType(ZsaEncShared* S, u32* repeatMode, const u32* count, u32 max, u32 mostFrequent, u32 nbSeq,
-                                   int kind, const ZsaFseCT* prevCT, u8* wksp, int isDefaultAllowed, u32 strategy)
+                                   int kind, const ZsaFseCT* prevCT, u8* wksp, int isDefaultAllowed, u32 strategy, int lane)
 {
     u32 const defaultNormLog = kind == 1 ? ZSA_OF_DEFAULTNORMLOG : 6;
     if (mostFrequent == nbSeq) {
@@ -898,43 +968,39 @@ ZSA_DEV u32 zsa_selectEncodingType(ZsaEncShared* S, u32* repeatMode, const u32* 
         }
     } else {
         u32 basicCost = ZSA_COST_ERROR, repeatCost = ZSA_COST_ERROR, compressedCost;
+        bool const mine = (u32)lane <= max;
+        u32 const c = mine ? count[lane] : 0;
         if (isDefaultAllowed) {
             u32 const shift = 8 - defaultNormLog;
-            u32 cost = 0;
-            for (u32 s = 0; s <= max; ++s) {
-                s32 const n = kind == 0 ? zsa_LL_defaultNorm(s) : (kind == 1 ? zsa_OF_defaultNorm(s) : zsa_ML_defaultNorm(s));
-                u32 const normAcc = (n != -1) ? (u32)n : 1;
-                cost += count[s] * zsa_invProbLog256(normAcc << shift);
-            }
-            basicCost = cost >> 8;
+            s32 const n = kind == 0 ? zsa_LL_defaultNorm((u32)lane) : (kind == 1 ? zsa_OF_defaultNorm((u32)lane) : zsa_ML_defaultNorm((u32)lane));
+            u32 const normAcc = (n != -1) ? (u32)n : 1;
+            basicCost = wv_reduce_add(mine ? c * zsa_invProbLog256(normAcc << shift) : 0u) >> 8;
         }
         if (*repeatMode != zsa_rep_none && prevCT && prevCT->maxSV >= max) {
             u32 const tableLog = prevCT->tableLog, badCost = (tableLog + 1) << 8;
-            u32 cost = 0;
-            bool bad = false;
-            for (u32 s = 0; s <= max; ++s) {
-                if (count[s] == 0) continue;
-                u32 const dnb = prevCT->dnb[s];
+            u32 bitCost = 0;
+            if (c != 0) {
+                u32 const dnb = prevCT->dnb[lane];
                 u32 const minNbBits = dnb >> 16;
                 u32 const threshold = (minNbBits + 1) << 16;
                 u32 const deltaFromThreshold = threshold - (dnb + (1u << tableLog));
-                u32 const bitCost = ((minNbBits + 1) << 8) - ((deltaFromThreshold << 8) >> tableLog);
-                if (bitCost >= badCost) { bad = true; break; }
-                cost += count[s] * bitCost;
+                bitCost = ((minNbBits + 1) << 8) - ((deltaFromThreshold << 8) >> tableLog);
             }
+            bool const bad = wv_ballot(c != 0 && bitCost >= badCost) != 0;
+            u32 const cost = wv_reduce_add(c * bitCost);
             if (!bad) repeatCost = cost >> 8;
         }
         {   u32 const FSELog = kind == 1 ? ZSA_OffFSELog : 9;
             u32 const tableLog = zsa_fse_optimalTableLog(FSELog, nbSeq, max, 2);
             u32 NCountCost = 0;
-            if (zsa_fse_normalizeCount(S->norm, tableLog, count, nbSeq, max, nbSeq >= 2048)) NCountCost = ZSA_COST_ERROR >> 3;
-            else NCountCost = zsa_fse_writeNCount(wksp, S->norm, max, tableLog);
-            u32 cost = 0;
-            for (u32 s = 0; s <= max; ++s) {
-                u32 norm = (256 * count[s]) / nbSeq;
-                if (count[s] != 0 && norm == 0) norm = 1;
-                cost += count[s] * zsa_invProbLog256(norm);
+            if (zsa_fse_normalizeCount_wave(S->norm, tableLog, count, nbSeq, max, nbSeq >= 2048, lane)) NCountCost = ZSA_COST_ERROR >> 3;
+            else {
+                if (lane == 0) NCountCost = zsa_fse_writeNCount(wksp, S->norm, max, tableLog);
+                NCountCost = wv_shfl(NCountCost, 0);
             }
+            u32 norm = (256 * c) / nbSeq;
+            if (c != 0 && norm == 0) norm = 1;
+            u32 const cost = wv_reduce_add(c != 0 ? c * zsa_invProbLog256(norm) : 0u);
             compressedCost = (NCountCost << 3) + (cost >> 8);
         }
         if (basicCost <= repeatCost && basicCost <= compressedCost) { *repeatMode = zsa_rep_none; return zsa_set_basic; }
@@ -943,40 +1009,53 @@ ZSA_DEV u32 zsa_selectEncodingType(ZsaEncShared* S, u32* repeatMode, const u32* 
     *repeatMode = zsa_rep_check;
     return zsa_set_compressed;
 }
-// zstd_compress_sequences.c:243-289 ZSTD_buildCTable; serial.  kind 0 LL, 1 OF, 2 ML.  Returns header bytes, sets *fail.
+// zstd_compress_sequences.c:243-289 ZSTD_buildCTable, by the whole wave.  kind 0 LL, 1 OF, 2 ML.  ct, count: LDS.  Returns header
+// bytes (wave-uniform), sets *fail.
 ZSA_DEV u32 zsa_buildSeqCTable(ZsaEncShared* S, u8* dst, ZsaFseCT* ct, int kind, u32 type, u32* count, u32 max,
-                               u32 lastCode, u32 firstCode, u32 nbSeq, const ZsaFseCT* dictTable, u32* fail)
+                               u32 lastCode, u32 firstCode, u32 nbSeq, const ZsaFseCT* dictTable, u32* fail, int lane)
 {
     u32 const FSELog = kind == 1 ? ZSA_OffFSELog : 9;
     switch (type) {
     case zsa_set_rle:
-        ct->tableLog = 0; ct->maxSV = max; ct->nextState[0] = 0; ct->nextState[1] = 0; ct->dnb[max] = 0; ct->dfs[max] = 0;
-        *dst = (u8)firstCode;
+        if (lane == 0) {
+            ct->tableLog = 0; ct->maxSV = max; ct->nextState[0] = 0; ct->nextState[1] = 0; ct->dnb[max] = 0; ct->dfs[max] = 0;
+            *dst = (u8)firstCode;
+        }
+        wv_lds_fence();
         return 1;
     case zsa_set_repeat:
         if (dictTable) {
-            for (u32 i = 0; i < 512; i++) ct->nextState[i] = dictTable->nextState[i];
-            for (u32 i = 0; i <= ZSA_MaxSeq; i++) { ct->dfs[i] = dictTable->dfs[i]; ct->dnb[i] = dictTable->dnb[i]; }
-            ct->tableLog = dictTable->tableLog; ct->maxSV = dictTable->maxSV;
+            for (u32 i = (u32)lane; i < 512; i += ZSA_WAVE) ct->nextState[i] = dictTable->nextState[i];
+            if ((u32)lane <= ZSA_MaxSeq) { ct->dfs[lane] = dictTable->dfs[lane]; ct->dnb[lane] = dictTable->dnb[lane]; }
+            if (lane == 0) { ct->tableLog = dictTable->tableLog; ct->maxSV = dictTable->maxSV; }
+            wv_lds_fence();
         }
         return 0;
     case zsa_set_basic: {
         u32 const dmax = kind == 0 ? ZSA_MaxLL : (kind == 1 ? ZSA_DefaultMaxOff : ZSA_MaxML);
         u32 const dlog = kind == 1 ? ZSA_OF_DEFAULTNORMLOG : 6;
-        for (u32 s = 0; s <= dmax; s++)
-            S->norm[s] = (s16)(kind == 0 ? zsa_LL_defaultNorm(s) : (kind == 1 ? zsa_OF_defaultNorm(s) : zsa_ML_defaultNorm(s)));
-        zsa_fse_buildCTable(S, ct->nextState, ct->dfs, ct->dnb, S->norm, dmax, dlog);
-        ct->tableLog = dlog; ct->maxSV = dmax;
+        if ((u32)lane <= dmax)
+            S->norm[lane] = (s16)(kind == 0 ? zsa_LL_defaultNorm((u32)lane) : (kind == 1 ? zsa_OF_defaultNorm((u32)lane) : zsa_ML_defaultNorm((u32)lane)));
+        wv_lds_fence();
+        zsa_fse_buildCTable_wave(S, ct->nextState, ct->dfs, ct->dnb, S->norm, dmax, dlog, lane);
+        if (lane == 0) { ct->tableLog = dlog; ct->maxSV = dmax; }
+        wv_lds_fence();
         return 0; }
     default: {
         u32 nbSeq_1 = nbSeq;
         u32 const tableLog = zsa_fse_optimalTableLog(FSELog, nbSeq, max, 2);
-        if (count[lastCode] > 1) { count[lastCode]--; nbSeq_1--; }
-        if (zsa_fse_normalizeCount(S->norm, tableLog, count, nbSeq_1, max, nbSeq_1 >= 2048)) { *fail = 1; return 0; }
-        u32 const NCountSize = zsa_fse_writeNCount(dst, S->norm, max, tableLog);
+        u32 const cLast = count[lastCode];
+        wv_lds_fence();
+        if (cLast > 1) { if (lane == 0) count[lastCode] = cLast - 1; nbSeq_1--; }
+        wv_lds_fence();
+        if (zsa_fse_normalizeCount_wave(S->norm, tableLog, count, nbSeq_1, max, nbSeq_1 >= 2048, lane)) { *fail = 1; return 0; }
+        u32 NCountSize = 0;
+        if (lane == 0) NCountSize = zsa_fse_writeNCount(dst, S->norm, max, tableLog);
+        NCountSize = wv_shfl(NCountSize, 0);
         if (NCountSize == 0) { *fail = 1; return 0; }
-        zsa_fse_buildCTable(S, ct->nextState, ct->dfs, ct->dnb, S->norm, max, tableLog);
-        ct->tableLog = tableLog; ct->maxSV = max;
+        zsa_fse_buildCTable_wave(S, ct->nextState, ct->dfs, ct->dnb, S->norm, max, tableLog, lane);
+        if (lane == 0) { ct->tableLog = tableLog; ct->maxSV = max; }
+        wv_lds_fence();
         return NCountSize; }
     }
 }
@@ -1017,30 +1096,33 @@ ZSA_DEV u32 zsa_entropyCompress(ZsaEncShared* S, const u64* seq, u32 nbSeq, cons
                 wv_atomic_add_lds(&S->count[c], 1);
             }
             wv_sync();
-            if (lane == 0) {
-                u32 max = kind == 0 ? ZSA_MaxLL : (kind == 1 ? ZSA_MaxOff : ZSA_MaxML);
-                while (!S->count[max]) max--;
-                u32 mostFrequent = 0;
-                for (u32 s = 0; s <= max; s++) if (S->count[s] > mostFrequent) mostFrequent = S->count[s];
+            {   // the table of this kind: decided and built by the whole wave, lane s <-> code s
+                u32 const cMine = (u32)lane <= ZSA_MaxSeq ? S->count[lane] : 0;
+                u32 const max = 63u - (u32)__builtin_clzll(wv_ballot(cMine != 0));      // (nbSeq > 0: some code occurs)
+                u32 const mostFrequent = wv_reduce_max(cMine);
                 u32* const rm = kind == 0 ? &S->nextLL : (kind == 1 ? &S->nextOF : &S->nextML);
+                u32 rmv = *rm;
                 int const defaultAllowed = kind == 1 ? (max <= ZSA_DefaultMaxOff) : 1;
                 // the table a "repeat" would use: the dictionary's, else (ZSTD_lazy and up) the parked one of the last
                 // compressed block of this frame
                 const ZsaFseCT* const dt = cd ? (kind == 0 ? &cd->ll : (kind == 1 ? &cd->of : &cd->ml)) : (park ? park + kind : (const ZsaFseCT*)0);
-                u32 const type = zsa_selectEncodingType(S, rm, S->count, max, mostFrequent, nbSeq, kind, cd ? (const ZsaFseCT*)0 : dt, tmp, defaultAllowed, strategy);
+                wv_lds_fence();
+                u32 const type = zsa_selectEncodingType(S, &rmv, S->count, max, mostFrequent, nbSeq, kind, cd ? (const ZsaFseCT*)0 : dt, tmp, defaultAllowed, strategy, lane);
                 u32 const lastCode = kind == 0 ? zsa_LLcode(zsa_seq_ll(lastSeq)) : (kind == 1 ? zsa_highbit32(zsa_seq_of(lastSeq)) : zsa_MLcode(zsa_seq_ml(lastSeq)));
                 u32 const firstCode = kind == 0 ? zsa_LLcode(zsa_seq_ll(firstSeq)) : (kind == 1 ? zsa_highbit32(zsa_seq_of(firstSeq)) : zsa_MLcode(zsa_seq_ml(firstSeq)));
                 ZsaFseCT* const ct = kind == 0 ? &S->ll : (kind == 1 ? &S->of : &S->ml);
                 u32 fail = 0;
-                u32 const cs = zsa_buildSeqCTable(S, op, ct, kind, type, S->count, max, lastCode, firstCode, nbSeq, dt, &fail);
-                if (fail) S->err = ZSA_GENERIC;
-                S->u[EU_s0 + kind] = type; S->u[EU_tmp] = cs;
+                u32 const cs = zsa_buildSeqCTable(S, op, ct, kind, type, S->count, max, lastCode, firstCode, nbSeq, dt, &fail, lane);
+                if (lane == 0) {
+                    *rm = rmv;
+                    if (fail) S->err = ZSA_GENERIC;
+                }
+                wv_sync();
+                if (S->err) return 0;
+                types[kind] = type;
+                if (type == zsa_set_compressed) lastCountSize = cs;
+                op += cs;
             }
-            wv_sync();
-            if (S->err) return 0;
-            types[kind] = S->u[EU_s0 + kind];
-            if (types[kind] == zsa_set_compressed) lastCountSize = S->u[EU_tmp];
-            op += S->u[EU_tmp];
             wv_sync();
         }
         ZSA_PROF(S, lane, 5);
