@@ -900,20 +900,34 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
 ZSA_DEV u64 zsa_rotl64(u64 x, int r) { return (x << r) | (x >> (64 - r)); }
 ZSA_DEV u64 zsa_xxh_round(u64 acc, u64 in) { acc += in * 0xC2B2AE3D27D4EB4FULL; acc = zsa_rotl64(acc, 31); return acc * 0x9E3779B185EBCA87ULL; }
 ZSA_DEV u64 zsa_xxh_merge(u64 acc, u64 v) { v = zsa_xxh_round(0, v); acc ^= v; return acc * 0x9E3779B185EBCA87ULL + 0x85EBCA77C2B2AE63ULL; }
-ZSA_DEV u64 zsa_xxh64(const u8* p, u64 len)
+// XXH64 of a decoded frame (xxhash.c XXH64_digest with seed 0; zstd_decompress.c:1040-1046), by the wave.  The bulk of the
+// hash is four independent accumulator chains over interleaved 8-byte words -- one lane each.  64 lanes fetch 512 bytes per
+// step with one coalesced load and park them in LDS, from where lanes 0-3 feed their chains, so no chain ever waits for
+// global memory; the (< 32 byte) tail and the avalanche are scalar work on lane 0.  Returns the hash in every lane.
+ZSA_DEV u64 zsa_xxh64(ZsaDecShared* S, const u8* p, u64 len, int lane)
 {
     const u64 P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL, P3 = 0x165667B19E3779F9ULL, P4 = 0x85EBCA77C2B2AE63ULL, P5 = 0x27D4EB2F165667C5ULL;
     const u8* const end = p + len;
+    u64* const stage = (u64*)S->seqLL;                 // 64 words (seqLL + seqML), free between blocks
+    u64 acc = lane == 0 ? P1 + P2 : (lane == 1 ? P2 : (lane == 2 ? 0 : 0 - P1));
+    u64 const nStripes = len >> 5;
+    for (u64 s0 = 0; s0 < nStripes; s0 += 16) {
+        u32 const cnt = (u32)((nStripes - s0) < 16 ? (nStripes - s0) : 16);
+        if ((u32)lane < 4 * cnt) stage[lane] = wv_ldg64(p + 32 * s0 + 8u * (u32)lane);
+        wv_lds_fence();
+        if (lane < 4) for (u32 k = 0; k < cnt; k++) acc = zsa_xxh_round(acc, stage[4 * k + (u32)lane]);
+        wv_lds_fence();
+    }
+    u32 const lo0 = wv_shfl((u32)acc, 0), hi0 = wv_shfl((u32)(acc >> 32), 0), lo1 = wv_shfl((u32)acc, 1), hi1 = wv_shfl((u32)(acc >> 32), 1);
+    u32 const lo2 = wv_shfl((u32)acc, 2), hi2 = wv_shfl((u32)(acc >> 32), 2), lo3 = wv_shfl((u32)acc, 3), hi3 = wv_shfl((u32)(acc >> 32), 3);
+    u64 const v1 = ((u64)hi0 << 32) | lo0, v2 = ((u64)hi1 << 32) | lo1, v3 = ((u64)hi2 << 32) | lo2, v4 = ((u64)hi3 << 32) | lo3;
     u64 h;
     if (len >= 32) {
-        const u8* const limit = end - 32;
-        u64 v1 = P1 + P2, v2 = P2, v3 = 0, v4 = 0 - P1;
-        do { v1 = zsa_xxh_round(v1, zsa_ld64(p)); v2 = zsa_xxh_round(v2, zsa_ld64(p + 8));
-             v3 = zsa_xxh_round(v3, zsa_ld64(p + 16)); v4 = zsa_xxh_round(v4, zsa_ld64(p + 24)); p += 32; } while (p <= limit);
         h = zsa_rotl64(v1, 1) + zsa_rotl64(v2, 7) + zsa_rotl64(v3, 12) + zsa_rotl64(v4, 18);
         h = zsa_xxh_merge(h, v1); h = zsa_xxh_merge(h, v2); h = zsa_xxh_merge(h, v3); h = zsa_xxh_merge(h, v4);
     } else h = P5;
     h += len;
+    p += nStripes << 5;
     while (p + 8 <= end) { h ^= zsa_xxh_round(0, zsa_ld64(p)); h = zsa_rotl64(h, 27) * P1 + P4; p += 8; }
     if (p + 4 <= end) { h ^= (u64)zsa_ld32(p) * P1; h = zsa_rotl64(h, 23) * P2 + P3; p += 4; }
     while (p < end) { h ^= (*p) * P5; h = zsa_rotl64(h, 11) * P1; p++; }
@@ -1041,9 +1055,8 @@ ZSA_DEV u64 zsa_decode_frames(ZsaDecShared* S, const u8* src, u64 srcSize, u8* d
         if (fcs != ~(u64)0 && op != fcs) return ZSA_ERR(ZSA_corruption_detected);
         if (checksumFlag) {
             if (remaining < 4) return ZSA_ERR(ZSA_checksum_wrong);
-            if (lane == 0) S->u[0] = (zsa_ld32(ip) != (u32)zsa_xxh64(dst, op));
-            wv_sync();
-            u32 const wrong = S->u[0];
+            wv_sync();   // (the frame's bytes were stored by many lanes)
+            bool const wrong = zsa_ld32(ip) != (u32)zsa_xxh64(S, dst, op, lane);
             wv_sync();
             if (wrong) return ZSA_ERR(ZSA_checksum_wrong);
             ip += 4; remaining -= 4;
