@@ -346,6 +346,31 @@ ZSA_DEV u32 zsa_huf_decodeStream(const ZsaDecShared* S, u8* p, u8* const pEnd, c
     u32 const dtLog = S->hufLog;
 #define ZSA_HUF_SYM() do { u32 const c = S->huf[zsa_br_lookFast(b, dtLog)]; *p++ = (u8)c; b.bitsConsumed += c >> 8; } while (0)
     if ((pEnd - p) > 3) {
+        // Interior of the stream: the same four-symbols-then-refill steps as the loop below (huf_decompress.c:570-666), with the
+        // refill taken out of the dependency chain.  The 8 bytes BELOW the window are requested one step ahead, so a refill is
+        // a funnel shift of two registers instead of a wait for memory, and the four symbols leave as one 4-byte store.
+        if (zsa_br_reload(b) == ZB_unfinished && b.ptr >= b.start + 16) {
+            const u8* ptr = b.ptr; u32 bc = b.bitsConsumed; u64 W = b.container;
+            u64 below = wv_ldg64(ptr - 8);
+            while (ptr >= b.start + 16 && p < pEnd - 3) {
+                u64 X = W << bc;
+                u32 out = 0;
+#pragma unroll
+                for (u32 k = 0; k < 4; k++) {
+                    u32 const c = S->huf[(u32)(X >> (64u - dtLog))];
+                    u32 const nbits = c >> 8;
+                    X <<= nbits; bc += nbits;
+                    out |= (c & 0xFFu) << (8u * k);
+                }
+                wv_stg32(p, out); p += 4;
+                u32 const nb = bc >> 3;            // <= 6: the step stays inside [start + 8, ...), the plain case of the refill
+                bc &= 7;
+                if (nb) W = (W << (8u * nb)) | (below >> (64u - 8u * nb));
+                ptr -= nb;
+                below = wv_ldg64(ptr - 8);
+            }
+            b.ptr = ptr; b.bitsConsumed = bc; b.container = W;
+        }
         while ((zsa_br_reload(b) == ZB_unfinished) & (p < pEnd - 3)) { ZSA_HUF_SYM(); ZSA_HUF_SYM(); ZSA_HUF_SYM(); ZSA_HUF_SYM(); }
     } else zsa_br_reload(b);
     while (p < pEnd) ZSA_HUF_SYM();
@@ -464,8 +489,9 @@ ZSA_DEV void zsa_copy_run32(u8* d, const u8* s, u32 len)
 
 // One compressed block.  op = output offset of the block inside the frame (relative to dstBase),
 // cap = remaining capacity.  Returns decoded size (uniform); on error S->err is set.
+// lastBlock: no later block of this frame can name this block's tables again, so they are not parked.
 ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 srcSize, u32 op, u64 cap,
-                             u8* litBuf, int lane)
+                             u8* litBuf, bool lastBlock, int lane)
 {
     ZsaDecBackup* const bk = (ZsaDecBackup*)(litBuf + ZSA_DEC_LITBUF_BYTES);
     u32 const expectedWriteSize = cap < ZSA_BLOCKSIZE_MAX ? (u32)cap : ZSA_BLOCKSIZE_MAX;
@@ -536,8 +562,7 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
             if (S->err) return 0;
             if (hSize >= cSrcSize) { if (lane == 0) zsa_raise(S, ZSA_corruption_detected); wv_sync(); return 0; }
             cSrc += hSize; cSrcSize -= hSize;
-            zsa_copy16(bk->huf, S->huf, 2u << S->hufLog, lane);   // a later block may repeat it
-            C.hufSrc = bk->huf;
+            if (!lastBlock) { zsa_copy16(bk->huf, S->huf, 2u << S->hufLog, lane); C.hufSrc = bk->huf; }   // a later block may repeat it
         } else {   // treeless: the table of an earlier block (or of the dictionary)
             zsa_copy16(S->huf, C.hufSrc, 2u << S->hufLog, lane);
             wv_sync();
@@ -624,11 +649,11 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
     if (S->u[ZU_nbSeq]) {   // tables built by this block are parked for later "repeat"s; repeated ones come back from there
         u32 const tLL = S->u[ZU_streams], tOF = S->u[ZU_hufOff], tML = S->u[ZU_hufCSize];
         if (tLL == zsa_set_repeat) zsa_copy16(S->ll, C.llSrc, 8u << S->llLog, lane);
-        else { zsa_copy16(bk->ll, S->ll, 8u << S->llLog, lane); C.llSrc = bk->ll; }
+        else if (!lastBlock) { zsa_copy16(bk->ll, S->ll, 8u << S->llLog, lane); C.llSrc = bk->ll; }
         if (tOF == zsa_set_repeat) zsa_copy16(S->of, C.ofSrc, 8u << S->ofLog, lane);
-        else { zsa_copy16(bk->of, S->of, 8u << S->ofLog, lane); C.ofSrc = bk->of; }
+        else if (!lastBlock) { zsa_copy16(bk->of, S->of, 8u << S->ofLog, lane); C.ofSrc = bk->of; }
         if (tML == zsa_set_repeat) zsa_copy16(S->ml, C.mlSrc, 8u << S->mlLog, lane);
-        else { zsa_copy16(bk->ml, S->ml, 8u << S->mlLog, lane); C.mlSrc = bk->ml; }
+        else if (!lastBlock) { zsa_copy16(bk->ml, S->ml, 8u << S->mlLog, lane); C.mlSrc = bk->ml; }
         wv_sync();
     }
 
@@ -689,16 +714,17 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                     u32 const llH = (u32)(ll >> 32), mlH = (u32)(ml >> 32), ofH = (u32)(of >> 32);
                     u32 const ofBits = (ofH >> 16) & 0xFF, mlBits = (mlH >> 16) & 0xFF, llBits = (llH >> 16) & 0xFF;
                     u32 const llS = llH >> 24, mlS = mlH >> 24, ofS = ofH >> 24;
-                    u32 const total = ofBits + mlBits + llBits + llS + mlS + ofS;
+                    // (the fields are cut from the top down: `at` = lowest bit of the field at hand, counted in the top 32 bits of the
+                    // window -- one subtraction and one bit-field extract per field, and 32 - at is the number of bits taken)
+                    u32 const at1 = 32u - ofBits, at2 = at1 - mlBits, at3 = at2 - llBits, at4 = at3 - llS, at5 = at4 - mlS, at6 = at5 - ofS;
                     u32 ofx, mlx, llx, sl, sm, so;
-                    u32 const used = bc + total;
-                    if (used <= 32) {   // the usual case: all six fields lie in the top 32 bits of the window, one bit-field extract each
+                    u32 const used = bc + 32u - at6;
+                    if ((s32)(at6 - bc) >= 0) {   // the usual case: all six fields lie in the top 32 bits of the window
                         u32 const top = (u32)((W << bc) >> 32);
-                        u32 const o1 = ofBits, o2 = o1 + mlBits, o3 = o2 + llBits, o4 = o3 + llS, o5 = o4 + mlS;
                         pOff -= used >> 3; bc = used & 7;
                         W = ((const Pk*)(S->bits + pOff))->v;
-                        ofx = wv_bfe(top, 32u - o1, ofBits); mlx = wv_bfe(top, 32u - o2, mlBits); llx = wv_bfe(top, 32u - o3, llBits);
-                        sl = wv_bfe(top, 32u - o4, llS); sm = wv_bfe(top, 32u - o5, mlS); so = wv_bfe(top, 32u - total, ofS);
+                        ofx = wv_bfe(top, at1, ofBits); mlx = wv_bfe(top, at2, mlBits); llx = wv_bfe(top, at3, llBits);
+                        sl = wv_bfe(top, at4, llS); sm = wv_bfe(top, at5, mlS); so = wv_bfe(top, at6, ofS);
                     } else
                     if (used <= 64) {
                         u64 X = W << bc;
@@ -1034,7 +1060,7 @@ ZSA_DEV u64 zsa_decode_frames(ZsaDecShared* S, const u8* src, u64 srcSize, u8* d
             u32 decoded;
             if (blockType == zsa_bt_compressed) {
                 if (op + ZSA_BLOCKSIZE_MAX > 0xFFFFFFFFull) return ZSA_ERR(ZSA_frameParameter_unsupported);   // frames >= 4 GiB: not this path
-                decoded = zsa_decode_block(S, C, ip, cBlockSize, (u32)op, cap, litBuf, lane);
+                decoded = zsa_decode_block(S, C, ip, cBlockSize, (u32)op, cap, litBuf, lastBlock != 0, lane);
                 if (S->err) return ZSA_ERR(S->err);
             } else if (blockType == zsa_bt_raw) {
                 if (cBlockSize > cap) return ZSA_ERR(ZSA_dstSize_tooSmall);
