@@ -1151,18 +1151,27 @@ ZSA_DEV u32 zsa_entropyCompress(ZsaEncShared* S, const u64* seq, u32 nbSeq, cons
                 }
                 wv_lds_fence();
                 if (lane < 3) {   // the three state chains, side by side
-                    for (u32 j = 0; j < cnt; j++) {
-                        u32 const sym = E->code[lane][j];
-                        if (tBase + j == 0) {   // FSE_initCState2 with the last sequence's code
-                            zsa_fse_initCState2(st, st.next, st.dfs, st.dnb, st.stateLog, sym);
-                            E->stBits[lane][j] = 0; E->stNb[lane][j] = 0;
-                        } else {
-                            u32 const nbBitsOut = (st.value + st.dnb[sym]) >> 16;
-                            E->stBits[lane][j] = (u16)(st.value & ((1u << nbBitsOut) - 1u));
-                            E->stNb[lane][j] = (u8)nbBitsOut;
-                            st.value = st.next[(s32)(st.value >> nbBitsOut) + st.dfs[sym]];
-                        }
+                    // One step = one table read that depends on the step before it.  What a step needs besides the state -- the
+                    // symbol's two transform words -- depends on the symbol only, so it is fetched four steps at a time ahead
+                    // of the chain: a step then costs one LDS round trip instead of four.
+                    const u8* const codes = E->code[lane];
+                    u32 j = 0;
+#define ZSA_CHAIN_STEP(dnbv, dfsv, jj) do { u32 const nbBitsOut = (st.value + (dnbv)) >> 16;                                   \
+                        E->stBits[lane][jj] = (u16)(st.value & ((1u << nbBitsOut) - 1u)); E->stNb[lane][jj] = (u8)nbBitsOut;      \
+                        st.value = st.next[(s32)(st.value >> nbBitsOut) + (dfsv)]; } while (0)
+                    if (tBase == 0) {   // FSE_initCState2 with the last sequence's code
+                        zsa_fse_initCState2(st, st.next, st.dfs, st.dnb, st.stateLog, codes[0]);
+                        E->stBits[lane][0] = 0; E->stNb[lane][0] = 0;
+                        j = 1;
                     }
+                    for (; j + 4 <= cnt; j += 4) {
+                        u32 const s0 = codes[j], s1 = codes[j + 1], s2 = codes[j + 2], s3 = codes[j + 3];
+                        u32 const b0 = st.dnb[s0], b1 = st.dnb[s1], b2 = st.dnb[s2], b3 = st.dnb[s3];
+                        s32 const f0 = st.dfs[s0], f1 = st.dfs[s1], f2 = st.dfs[s2], f3 = st.dfs[s3];
+                        ZSA_CHAIN_STEP(b0, f0, j); ZSA_CHAIN_STEP(b1, f1, j + 1); ZSA_CHAIN_STEP(b2, f2, j + 2); ZSA_CHAIN_STEP(b3, f3, j + 3);
+                    }
+                    for (; j < cnt; j++) { u32 const sy = codes[j]; u32 const bv = st.dnb[sy]; s32 const fv = st.dfs[sy]; ZSA_CHAIN_STEP(bv, fv, j); }
+#undef ZSA_CHAIN_STEP
                 }
                 wv_lds_fence();
                 // this sequence's bits, in emission order: OF/ML/LL state bits, then LL/ML/OF extra bits
