@@ -201,3 +201,28 @@ struct ZsaFrameDesc {
     const u8* src; u8* dst;
     u64 srcSize; u64 dstCapacity;
 };
+
+// Copies len <= 32 bytes from s to d (global memory, not overlapping), each lane its own run: up to four 8-byte moves -- at
+// 0, 8, 16 and at len - 8, which covers the end whatever len is -- or two 4-byte moves, or single bytes below 4.  All loads are
+// issued before the first store, so a lane's moves share one memory round trip.
+ZSA_DEV void zsa_copy_run32(u8* d, const u8* s, u32 len)
+{
+    if (len >= 8) {
+        u64 const a = wv_ldg64(s), t = wv_ldg64(s + len - 8);
+        u64 b = 0, c = 0;
+        if (len > 16) b = wv_ldg64(s + 8);
+        if (len > 24) c = wv_ldg64(s + 16);
+        wv_stg64u(d, a);
+        if (len > 16) wv_stg64u(d + 8, b);
+        if (len > 24) wv_stg64u(d + 16, c);
+        wv_stg64u(d + len - 8, t);
+    } else if (len >= 4) {
+        u32 const a = wv_ldg32(s), t = wv_ldg32(s + len - 4);
+        wv_stg32(d, a); wv_stg32(d + len - 4, t);
+    } else if (len) {
+        u32 const a = wv_ldg8(s), b = len > 1 ? wv_ldg8(s + 1) : 0, c = len > 2 ? wv_ldg8(s + 2) : 0;
+        wv_stg8(d, a);
+        if (len > 1) wv_stg8(d + 1, b);
+        if (len > 2) wv_stg8(d + 2, c);
+    }
+}

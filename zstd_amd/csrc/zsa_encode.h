@@ -1256,16 +1256,22 @@ ZSA_DEV void zsa_gatherLiterals(ZsaEncShared* S, const u64* seq, u32 nbSeq, cons
         u32 const ll = (u32)lane < n ? zsa_seq_ll(s) : 0;
         u32 const tot = (u32)lane < n ? ll + zsa_seq_ml(s) + ZSA_MINMATCH : 0;
         u32 const litIncl = wv_scan_incl(ll), totIncl = wv_scan_incl(tot);
-        S->bLit[lane] = litIncl - ll; S->bSrc[lane] = totIncl - tot;
-        wv_sync();
         u32 const totalLit = wv_shfl(litIncl, 63), totalSrc = wv_shfl(totIncl, 63);
-        for (u32 t = (u32)lane; t < totalLit; t += ZSA_WAVE) {
-            u32 lo = 0, hi = n - 1;
-            while (lo < hi) { u32 const mid = (lo + hi + 1) >> 1; if (S->bLit[mid] <= t) lo = mid; else hi = mid - 1; }
-            lit[litPos + t] = src[srcPos + S->bSrc[lo] + (t - S->bLit[lo])];
+        // Runs of up to 32 bytes (nearly all of them on text-like data) are moved by the lane that owns the sequence, 8 bytes
+        // per instruction; a batch with a longer run is flattened over the lanes byte by byte.
+        if (!wv_ballot(ll > 32)) {
+            if ((u32)lane < n) zsa_copy_run32(lit + litPos + (litIncl - ll), src + srcPos + (totIncl - tot), ll);
+        } else {
+            S->bLit[lane] = litIncl - ll; S->bSrc[lane] = totIncl - tot;
+            wv_lds_fence();
+            for (u32 t = (u32)lane; t < totalLit; t += ZSA_WAVE) {
+                u32 lo = 0, hi = n - 1;
+                while (lo < hi) { u32 const mid = (lo + hi + 1) >> 1; if (S->bLit[mid] <= t) lo = mid; else hi = mid - 1; }
+                lit[litPos + t] = src[srcPos + S->bSrc[lo] + (t - S->bLit[lo])];
+            }
+            wv_lds_fence();
         }
         litPos += totalLit; srcPos += totalSrc;
-        wv_sync();
     }
     for (u32 t = (u32)lane; t < lastLL; t += ZSA_WAVE) lit[litPos + t] = src[srcSize - lastLL + t];
 }
