@@ -586,6 +586,7 @@ ZSA_DEVFN void zsa_parse_chunk(const ZsaTabFilt T, u32* ringWords, const ZsaPars
     u32 ipStop = 0;                                         // beyond it no pair can be decided here: min(winB + min(61, winValid - 2), nextStep - 7)
     u64 winH = 0;                                           // lanes whose probe passes the filter
     u64 wv64 = 0; u32 whash = 0, wcell = 0, wnib = 0;       // per lane: source word, cell number, own cell value, filter nibble at set-up
+    u32 wcand = 0;                                          // per lane with a table hit: the candidate's position
     u32 insV = 0;                                           // per lane: the position entered the table since set-up (not yet written)
     u32 lateA = 0, lateB = 0;                               // positions beyond the chunk that enter the table after what is pending
     u32* const tabP = T.p;
@@ -659,6 +660,17 @@ ZSA_DEVFN void zsa_parse_chunk(const ZsaTabFilt T, u32* ringWords, const ZsaPars
             {   u32 const a = winEnd - 2, b = nextStep - 7;   // (winB + min(61, winValid - 2))
                 ipStop = a < b ? a : b;
             }
+            // The table does not change while the chunk is scanned (commits are deferred), so the cells are fetched here, once per
+            // chunk and for all lanes that pass the filter at the same time, instead of once per event in the event's own
+            // dependency chain: a cell gives the candidate's position and the fingerprint bits the filter does not hold, and
+            // winH keeps the lanes whose whole fingerprint agrees.  (Measured: fetching the candidates' bytes here as well --
+            // 8 on either side, so that short matches need no memory at all -- adds nothing on top of this.)
+            {   bool const probe = ((winH >> lane) & 1) != 0 && (u32)lane < winValid;
+                u32 cx = 1u << posBits;
+                if (probe) cx = wv_ldg_cell(tabP + whash) ^ wcell;
+                wcand = (cx & posMask) ^ q;                                      // (the low bits of wcell are q)
+                winH = wv_ballot((cx >> posBits) == 0 && wcand >= prefixStartIndex);
+            }
         }
         u32 const o = ip0 - winB;
         u32 lim;   // twice the number of pairs decided here, >= 2: both lanes of a pair below winValid, the repcode lane ip0 + 2i + 2 <= 63,
@@ -693,13 +705,9 @@ ZSA_DEVFN void zsa_parse_chunk(const ZsaTabFilt T, u32* ringWords, const ZsaPars
             continue;
         }
         u32 const cur = ip0 + (isRep ? fr : (isHash ? fh : 0u));         // where the event is
-        // a table event: the winning lane reads its cell -- position, and the fingerprint bits the filter does not hold
+        // a table event: the candidate position was fetched when the chunk was set up
         u32 const L = (o + fh) & 63u;
-        u32 x = 0;
-        if ((u32)lane == L && isHash) x = wv_ldg_cell(tabP + whash) ^ wcell;
-        x = wv_readlane(x, (int)L);
-        u32 const m = isHash ? ((x & posMask) ^ cur) : cur - (isR2 ? rep2 : rep1);
-        if (isHash && ((x >> posBits) != 0 || m < prefixStartIndex)) { ZSA_STAT(6); winH &= ~(1ull << L); continue; }   // the filter let it through: not an event
+        u32 const m = isHash ? wv_readlane(wcand, (int)L) : cur - (isR2 ? rep2 : rep1);
         // one round of match extension: lanes 0..15 compare 8 bytes each forwards from (cur + four, m + four), lanes
         // 48..63 one byte each backwards from (cur - 1, m - 1) for at most eBack bytes (the source side lies in the ring;
         // a candidate older than the ring costs one or two lines).  A repcode's 4 bytes are known to match (:259-265).
