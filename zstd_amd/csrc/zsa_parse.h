@@ -695,8 +695,10 @@ ZSA_DEVFN void zsa_parse_chunk(const ZsaTabFilt T, u32* ringWords, const ZsaPars
             fr = Rs ? (u32)__builtin_ctzll(Rs) : 64u;
             if (fr > lim || rep1 == 0) fr = 64;
         }
-        u32 const isRep = (isR2 == 0 && fr != 64 && fr <= fh + 2) ? 1u : 0u;
-        u32 const isHash = (isR2 == 0 && isRep == 0 && fh != 64) ? 1u : 0u;
+        // (flags by integer arithmetic -- fh, fr are in [0, 64] -- so that they stay 32-bit scalars: written as comparisons the
+        // compiler turns each of them into a 64-bit lane mask and back)
+        u32 const isRep = (isR2 ^ 1u) & ((127u - fr) >> 6) & (((fh + 2u - fr) >> 31) ^ 1u);          // no R2, fr != 64, fr <= fh + 2
+        u32 const isHash = (isR2 ^ 1u) & (isRep ^ 1u) & ((127u - fh) >> 6);                          // neither, fh != 64
         if ((isR2 | isRep | isHash) == 0) {   // no event: all pairs enter the table, the search goes on
             ZSA_STAT(2);
             insV |= ((u32)lane - o < lim) ? 1u : 0u;
@@ -704,7 +706,7 @@ ZSA_DEVFN void zsa_parse_chunk(const ZsaTabFilt T, u32* ringWords, const ZsaPars
             mid = 1;
             continue;
         }
-        u32 const cur = ip0 + (isRep ? fr : (isHash ? fh : 0u));         // where the event is
+        u32 const cur = ip0 + isRep * fr + isHash * fh;                  // where the event is
         // a table event: the candidate position was fetched when the chunk was set up
         u32 const L = (o + fh) & 63u;
         u32 const m = isHash ? wv_readlane(wcand, (int)L) : cur - (isR2 ? rep2 : rep1);
