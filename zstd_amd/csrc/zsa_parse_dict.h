@@ -16,6 +16,10 @@
 // Included by zsa_encode.h (uses zsa_hash, zsa_packseq, ZsaEncParams, ZsaCDictDev, ZsaWindow from there).
 #pragma once
 
+#ifndef ZSA_DMS_W0
+#define ZSA_DMS_W0 16u     // positions in the first window of a search (attached-dictionary parse)
+#endif
+
 struct ZsaDmsView {       // one index space over dictionary + payload
     const u8* base;       // index i >= prefix <-> base + i
     const u8* dbase;      // index i <  prefix <-> dbase + i   (dictionary content, shifted by dictIndexDelta)
@@ -39,19 +43,29 @@ ZSA_DEV u32 zsa_dv_count(const ZsaDmsView& V, u32 ip, u32 m, u32 iend, int lane)
         total += ZSA_WAVE;
     }
 }
-// bytes that match backwards from (ip - 1, m - 1): ip stays above `anchor`, m above `low` (zstd_fast.c:569-573, :583-588)
-ZSA_DEV u32 zsa_dv_back(const ZsaDmsView& V, u32 ip, u32 m, u32 anchor, u32 low, int lane)
+// a table match measured in both directions -- forwards from (ip + 4, m + 4), backwards from (ip - 1, m - 1), where ip stays
+// above `anchor` and m above `low` (zstd_fast.c:569-573, :583-588) -- the first 64 bytes of each direction in one round trip
+ZSA_DEV void zsa_dv_extend(const ZsaDmsView& V, u32 ip, u32 m, u32 iend, u32 anchor, u32 low, u32* fwd, u32* bwd, int lane)
 {
     u32 const room = (ip - anchor) < (m - low) ? (ip - anchor) : (m - low);
-    u32 total = 0;
-    while (total < room) {
-        u32 const k = total + (u32)lane;
-        bool const same = k < room && wv_ldg8(V.base + ip - 1 - k) == zsa_dv8(V, m - 1 - k);
-        u64 const stop = wv_ballot(!same);
-        if (stop) return total + (u32)__builtin_ctzll(stop);
-        total += ZSA_WAVE;
+    u32 const a = ip + 4 + (u32)lane;
+    bool const fin = a < iend, bin = (u32)lane < room;
+    u32 const f0 = wv_ldg8(V.base + (fin ? a : ip)), f1 = zsa_dv8(V, fin ? m + 4 + (u32)lane : m);
+    u32 const b0 = wv_ldg8(V.base + (bin ? ip - 1 - (u32)lane : ip)), b1 = zsa_dv8(V, bin ? m - 1 - (u32)lane : m);
+    u64 const fstop = wv_ballot(!(fin && f0 == f1)), bstop = wv_ballot(!(bin && b0 == b1));
+    *fwd = fstop ? (u32)__builtin_ctzll(fstop) : ZSA_WAVE + zsa_dv_count(V, ip + 4 + ZSA_WAVE, m + 4 + ZSA_WAVE, iend, lane);
+    if (bstop) *bwd = (u32)__builtin_ctzll(bstop);              // (a lane at or beyond `room` counts as a mismatch)
+    else {   // more than 64 bytes backwards: rare
+        u32 total = ZSA_WAVE;
+        while (total < room) {
+            u32 const k = total + (u32)lane;
+            bool const same = k < room && wv_ldg8(V.base + ip - 1 - k) == zsa_dv8(V, m - 1 - k);
+            u64 const stop = wv_ballot(!same);
+            if (stop) { total += (u32)__builtin_ctzll(stop); break; }
+            total += ZSA_WAVE;
+        }
+        *bwd = total;
     }
-    return total;
 }
 
 // Parses one block with the dictionary `Wn.dms` attached.  hashTable: the frame's local table (global scratch, zeroed).
@@ -82,12 +96,13 @@ ZSA_DEVFN u32 zsa_parse_dms_wave(u32* hashTable, u32 hlog, u32 mls, u32 tlen, co
     u32 off1 = wv_uniform(rep[0]), off2 = wv_uniform(rep[1]), nbSeq = 0;
     ip0 += ((istart - prefix) + dms->contentSize == 0);         // :497 dictAndPrefixLength == 0
     u32 step = stepSize, nextStep = ip0 + 256;                  // :533, kStepIncr = 1 << 8
+    u32 width = ZSA_DMS_W0;                                     // positions per window: narrow after a match, doubling while nothing is found
     if (srcSize >= 8 + stepSize)   // (ilimit does not wrap)
     for (;;) {   // one window per iteration
         // positions: consecutive while the step is 1, up to and including the first one at or beyond nextStep (whose own
         // step is 2); beyond that one position per window
         u32 nAct = 1;
-        if (step == 1) { u32 const a = nextStep - ip0 + 1; nAct = a < ZSA_WAVE ? a : ZSA_WAVE; }
+        if (step == 1) { u32 const a = nextStep - ip0 + 1; nAct = a < width ? a : width; }
         u32 const cur = ip0 + (u32)lane;
         u32 const myStep = step + ((lane > 0 && cur >= nextStep) ? 1u : 0u);
         bool const valid = (u32)lane < nAct && cur + myStep <= ilimit;       // the reference reaches it (:530, :618)
@@ -121,16 +136,18 @@ ZSA_DEVFN u32 zsa_parse_dms_wave(u32* hashTable, u32 hlog, u32 mls, u32 tlen, co
         bool const mine = (u32)lane < nEff;
         // the three checks of a position (:536-592)
         u32 kind = 0;   // 1: repcode at cur + 1, 2: dictionary, 3: local table
-        if (mine) {
+        {   // the bytes of all three candidates in one round trip (a lane without one reads the block's first bytes)
             u32 const repIndex = cur + 1 - off1;
             u32 const w0 = (u32)v, w1 = (u32)(v >> 8);
-            if ((u32)((prefix - 1) - repIndex) >= 3 && zsa_dv32(V, repIndex) == w1) kind = 1;
-            else {
-                bool const tagsMatch = (dcell & 0xFFu) == (dh & 0xFFu);
-                u32 const dIdx = dcell >> 8;
-                if (tagsMatch && dIdx > 2 && mIdx <= prefix && wv_ldg32(dms->content - 2 + dIdx) == w0) kind = 2;
-                else if (mIdx > prefix && wv_ldg32(V.base + mIdx) == w0) kind = 3;
-            }
+            u32 const dIdx = dcell >> 8;
+            bool const repTry = mine && (u32)((prefix - 1) - repIndex) >= 3;
+            bool const dTry = mine && (dcell & 0xFFu) == (dh & 0xFFu) && dIdx > 2 && mIdx <= prefix;
+            bool const lTry = mine && mIdx > prefix;
+            u32 cR = zsa_dv32(V, repTry ? repIndex : istart);
+            u32 cD = wv_ldg32(dTry ? dms->content - 2 + dIdx : V.base + istart);
+            u32 cL = wv_ldg32(V.base + (lTry ? mIdx : istart));
+            wv_join(cR, cD, cL);
+            kind = (repTry && cR == w1) ? 1u : ((dTry && cD == w0) ? 2u : ((lTry && cL == w0) ? 3u : 0u));
         }
         u64 const found = wv_ballot(kind != 0);
         u32 const nIns = found ? (u32)__builtin_ctzll(found) + 1 : nEff;     // positions that enter the local table (:535)
@@ -144,6 +161,7 @@ ZSA_DEVFN u32 zsa_parse_dms_wave(u32* hashTable, u32 hlog, u32 mls, u32 tlen, co
             if (s != step) { step = s; nextStep += 256; }
             ip0 = last + step;
             if (ip0 >= nextStep) { step++; nextStep += 256; }
+            width = width * 2 < ZSA_WAVE ? width * 2 : ZSA_WAVE;
             continue;
         }
         int const e = __builtin_ctzll(found);
@@ -156,8 +174,8 @@ ZSA_DEVFN u32 zsa_parse_dms_wave(u32* hashTable, u32 hlog, u32 mls, u32 tlen, co
         } else {
             u32 const m = eKind == 2 ? (wv_readlane(dcell, e) >> 8) + dictIndexDelta : wv_readlane(mIdx, e);
             u32 const low = eKind == 2 ? V.dictLow : prefix;
-            u32 const fwd = zsa_dv_count(V, curE + 4, m + 4, iend, lane);
-            u32 const bwd = zsa_dv_back(V, curE, m, anchor, low, lane);
+            u32 fwd, bwd;
+            zsa_dv_extend(V, curE, m, iend, anchor, low, &fwd, &bwd, lane);
             start = curE - bwd;
             mLength = 4 + fwd + bwd;
             off2 = off1; off1 = curE - m;
@@ -194,6 +212,7 @@ ZSA_DEVFN u32 zsa_parse_dms_wave(u32* hashTable, u32 hlog, u32 mls, u32 tlen, co
             }
         }
         step = stepSize; nextStep = ip0 + 256;                  // :530-533 a new search
+        width = ZSA_DMS_W0;
         if (ip0 + step > ilimit) break;
     }
     if (lane == 0) { rep[0] = off1; rep[1] = off2; rep[2] = iend - anchor; }   // :625-629 (no offset is ever set aside in this variant)
@@ -350,8 +369,8 @@ ZSA_DEVFN u32 zsa_parse_ext_wave(u32* hashTable, u32 hlog, u32 mls, u32 tlen, u3
             int const e = 2 * (int)ePair + (eRole == 2);
             u32 const m = wv_readlane(mIdx, e);
             u32 const low = m < prefix ? dictStart : prefix;
-            u32 const fwd = zsa_dv_count(V, current0 + 4, m + 4, iend, lane);
-            u32 const bwd = zsa_dv_back(V, current0, m, anchor, low, lane);
+            u32 fwd, bwd;
+            zsa_dv_extend(V, current0, m, iend, anchor, low, &fwd, &bwd, lane);
             start = current0 - bwd;
             mLength = 4 + fwd + bwd;
             off2 = off1; off1 = current0 - m;
