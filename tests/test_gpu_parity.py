@@ -224,6 +224,35 @@ def test_bulk_processor_matches_golden(z):
         assert one == got[2] and bp.Decompress(None, one) == srcs[2]
 
 
+def test_bulk_processor_seeded_payloads(z, oracle):
+    """Seeded payloads of 1 B .. 300 KB against every fixture dictionary, at the two ZSTD_fast levels the engine serves with a
+    dictionary: attached (<= 8 KiB), external segment (above; multi-block payloads, steps that have grown over incompressible
+    stretches before dictionary content turns up, matches that run from the dictionary into the payload) and re-loaded
+    dictionaries -- each frame byte-identical to the oracle's and round-tripped."""
+    from test_oracle_dict import load_dict_cases
+    from zstd_amd import corpus
+    dicts = load_dict_cases()[0]
+    rnd = random.Random(5)
+    for dn in sorted(dicts):
+        d = dicts[dn]
+        srcs = []
+        for n in (1, 300, 1024, 8192, 8193, 20000, 131084, 201820, 300000):
+            k = rnd.randrange(4)
+            if k == 0: p = corpus.frames("json", n, 1, rnd.randrange(1000))[0]
+            elif k == 1: p = corpus.frames("log", n, 1, rnd.randrange(1000))[0]
+            elif k == 2: p = ((d[-rnd.randrange(1, min(len(d), 3000) + 1):] + rnd.randbytes(50)) * (n // 200 + 1))[:n]
+            else: p = (bytes(rnd.choice(b"abc") for _ in range(n // 3)) + rnd.randbytes(n // 3) + d[:n - 2 * (n // 3)])[:n]
+            srcs.append(p)
+        for level in (1, -1):
+            bp = z.NewBulkProcessor(d, level)
+            cd = oracle.cdict(d, level)
+            got = bp.CompressBatch(srcs)
+            for p, g in zip(srcs, got):
+                assert g == oracle.compress_cdict(p, cd), (dn, level, len(p))
+            oracle.free_cdict(cd)
+            assert bp.DecompressBatch(got, [max(len(p), 1) for p in srcs]) == srcs
+
+
 def test_bulk_processor_go_cases(z, oracle):
     # zstd_bullk_test.go:62-81, 83-99, 101-126, 182-199, 227-250
     import base64
