@@ -18,6 +18,10 @@
 #pragma once
 #include "zsa_common.h"
 
+#ifndef ZSA_DEP_FENCE
+#define ZSA_DEP_FENCE() wv_lds_fence()
+#endif
+
 // ---- packed sequence-table cell: baseValue | nextState<<32 | nbAdditionalBits<<48 | nbBits<<56
 typedef u64 ZsaSeqCell;
 ZSA_DEV ZsaSeqCell zsa_seqcell(u32 base, u32 nextState, u32 addBits, u32 nbBits)
@@ -850,27 +854,53 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                 s64 const p = (s64)o - (s64)off + (off >= ml ? k : k % off);
                 dst[o + k] = p < 0 ? C.dictContent[(s64)C.dictSize + p] : dst[p];
             }
-            if (depMask) wv_sync();   // phase II may read the literals and the phase-I matches of this batch
-            // Phase II: the others, in order.  Only a match whose source reaches the output of an earlier phase-II match that
-            // has not been waited for yet needs another wait (`pending` = lowest such output position).
-            u32 pending = 0xFFFFFFFFu;
-            for (u64 m = depMask; m; m &= m - 1) {
-                u32 const i = (u32)__builtin_ctzll(m);
-                u32 const ml = S->seqML[i], off = S->seqOF[i];
-                u32 const o = outPos + S->outStart[i] + S->seqLL[i];
-                u32 const span = off < ml ? off : ml;            // distinct source bytes
-                if ((u64)o + span > (u64)off + pending) { wv_sync(); pending = 0xFFFFFFFFu; }
-                if (o < pending) pending = o;
-                if (off >= ml) {
-                    for (u32 t = (u32)lane; t < ml; t += ZSA_WAVE) {
-                        s64 const p = (s64)o - (s64)off + t;
-                        dst[o + t] = p < 0 ? C.dictContent[(s64)C.dictSize + p] : dst[p];
+            // Phase II: the others.  A match may run as soon as every dependent match that produces part of its source has run; the
+            // sequences its in-batch source bytes come from are a range of lanes (two searches in the output prefix sums),
+            // and any not-yet-done dependent match in that range holds it back.  All matches that are ready run in the same
+            // ROUND -- the short ones each on its own lane, so their loads share one memory round trip -- and a round ends with
+            // a wave-scope fence: the rounds of a batch are as many as its longest dependency chain, not as many as its
+            // dependent matches.
+            if (depMask) {
+                ZSA_DEP_FENCE();   // phase II may read the literals and the phase-I matches of this batch
+                bool const dep = ((depMask >> lane) & 1) != 0;
+                u64 needMask = 0;
+                if (dep) {
+                    s64 const a = (s64)myO - (s64)myOF;
+                    u32 const aRel = a <= (s64)outPos ? 0u : (u32)(a - (s64)outPos);
+                    u32 const bRel = (u32)(a + (s64)mySpan - (s64)outPos) - 1u;          // (dependent: its source ends inside the batch)
+                    u32 sA = 0, sB = 0;
+                    for (u32 b = 32; b; b >>= 1) {
+                        u32 const tA = sA + b, tB = sB + b;
+                        if (tA < n && S->outStart[tA] <= aRel) sA = tA;
+                        if (tB < n && S->outStart[tB] <= bRel) sB = tB;
                     }
-                } else {
-                    for (u32 t = (u32)lane; t < ml; t += ZSA_WAVE) {
-                        s64 const p = (s64)o - (s64)off + (t % off);
-                        dst[o + t] = p < 0 ? C.dictContent[(s64)C.dictSize + p] : dst[p];
+                    u64 const upTo = sB >= 63 ? ~0ull : ((2ull << sB) - 1ull);
+                    needMask = upTo & ~((1ull << sA) - 1ull) & (((u64)1 << lane) - 1ull) & depMask;
+                }
+                u64 notDone = depMask;
+                while (notDone) {
+                    bool const ready = dep && ((notDone >> lane) & 1) != 0 && (needMask & notDone) == 0;
+                    u64 const R = wv_ballot(ready);      // (never empty: the lowest match not yet done waits for nothing)
+                    bool const own = ready && myML <= 32 && myOF >= myML && myO >= myOF;
+                    if (own) zsa_copy_run32(dst + myO, dst + myO - myOF, myML);
+                    for (u64 m = wv_ballot(ready && !own); m; m &= m - 1) {
+                        u32 const i = (u32)__builtin_ctzll(m);
+                        u32 const ml = S->seqML[i], off = S->seqOF[i];
+                        u32 const o = outPos + S->outStart[i] + S->seqLL[i];
+                        if (off >= ml) {
+                            for (u32 t = (u32)lane; t < ml; t += ZSA_WAVE) {
+                                s64 const p = (s64)o - (s64)off + t;
+                                dst[o + t] = p < 0 ? C.dictContent[(s64)C.dictSize + p] : dst[p];
+                            }
+                        } else {
+                            for (u32 t = (u32)lane; t < ml; t += ZSA_WAVE) {
+                                s64 const p = (s64)o - (s64)off + (t % off);
+                                dst[o + t] = p < 0 ? C.dictContent[(s64)C.dictSize + p] : dst[p];
+                            }
+                        }
                     }
+                    notDone &= ~R;
+                    if (notDone) ZSA_DEP_FENCE();
                 }
             }
             outPos += totalOut; litPos += totalLit;
