@@ -98,6 +98,30 @@ def test_emulated_dictionary_path_matches_golden(emu):
     assert not emu.emu_create_cdict(bad, len(bad), 1) and not emu.emu_create_ddict(bad, len(bad))
 
 
+def test_emulated_dictionary_parsers_seeded(emu, oracle):
+    """zsa_parse_dict.h against the oracle on seeded payloads the fixture does not hold: the external-segment parser with
+    steps that have grown over an incompressible stretch before dictionary content turns up (where the position after a pair
+    lies beyond the match: the insert of zstd_fast.c:870-873 must not happen), multi-block payloads, matches that run from
+    the dictionary into the payload; the attached parser on small ones."""
+    from test_oracle_dict import load_dict_cases
+    dicts = load_dict_cases()[0]
+    rnd = random.Random(8)
+    d = dicts["raw_log_112k"]
+    n = 201820
+    big = bytes(rnd.choice(b"abc") for _ in range(100000)) + rnd.randbytes(100000) + d[:n - 200000]
+    cases = [("raw_log_112k", big), ("raw_log_4k", (dicts["raw_log_4k"][-700:] + rnd.randbytes(50)) * 30),
+             ("trained_json_8k", corpus.frames("json", 9000, 1, 5)[0]), ("trained_json_8k", corpus.frames("json", 1000, 1, 6)[0]),
+             ("raw_json_40k", rnd.randbytes(9000) + dicts["raw_json_40k"][:9000])]
+    for dn, p in cases:
+        cd = emu.emu_create_cdict(dicts[dn], len(dicts[dn]), 1)
+        ocd = oracle.cdict(dicts[dn], 1)
+        cap = zstd_amd.CompressBound(len(p))
+        buf = ctypes.create_string_buffer(cap + 1)
+        r = emu.emu_compress_cdict(buf, cap, p, len(p), cd)
+        assert buf.raw[:r] == oracle.compress_cdict(p, ocd), (dn, len(p))
+        emu.emu_free_cdict(cd); oracle.free_cdict(ocd)
+
+
 def test_emulated_dfast_parse_matches_oracle(emu, oracle):
     """zsa_dfast.h (levels 2-4 where the strategy is ZSTD_dfast) through the whole frame encoder"""
     cases = [b"", b"abc", corpus.frames("json", 1000, 1, 7)[0], corpus.frames("log", 20000, 1, 5)[0], corpus.frames("json", 70000, 1, 3)[0],
