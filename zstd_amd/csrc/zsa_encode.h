@@ -59,7 +59,8 @@ struct ZsaSeqEncScratch { u8 code[3][64]; u16 stBits[3][64]; u8 stNb[3][64]; u32
 // ZSTD_lazy the FSE sequence tables of a block are never used again (set_repeat is only reachable with dictionary
 // tables, which are re-read from the digest: zstd_compress_sequences.c:180-205); from ZSTD_lazy on a later block may
 // price and repeat them (:206-232), so they are parked in the workgroup's global scratch (ZsaEncScratch::park).
-#define ZSA_FILT_HLOG_MAX 13u     // the chunk path's LDS filter covers match tables of up to 1 << 13 cells
+#define ZSA_FILT_HLOG_MAX 13u     // the chunk path's LDS filter: 4 bits per cell for match tables of up to 1 << 13 cells,
+                                  // 2 bits per cell for 1 << 14 (256 KiB level-1 frames)
 struct ZsaEncShared {
     union {
         struct {   // entropy stages
@@ -1401,7 +1402,7 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
     u32 fpPosBits = 0;
     if (!cd && P.strat == 1) { u32 const bits = 32u - (u32)__builtin_clz(srcSize + 2u); if (bits <= 26u) fpPosBits = bits; }
     // chunk path (zsa_parse.h): levels 1-2 (step 2) with a table the LDS filter covers
-    bool const chunkParse = FAMILY == 2 && fpPosBits != 0 && P.tlen <= 1 && P.hlog <= ZSA_FILT_HLOG_MAX;
+    bool const chunkParse = FAMILY == 2 && fpPosBits != 0 && P.tlen <= 1 && P.hlog <= ZSA_FILT_HLOG_MAX + 1;
     int const literalsDisabled = (P.strat == 1) && (P.tlen > 0);   // zstd_compress_internal.h:605-618
     u32 const maxDist = 1u << P.wlog;
     ZsaLazyCtx LZ;   // greedy / lazy / lazy2 (zsa_lazy.h): match-finder state that lives across the blocks of the frame
@@ -1502,11 +1503,12 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
                     wv_sync();
                     if (chunkParse) {   // level 1 / 2: chunk path with the table's filter in LDS
                         u32 const cells = 1u << P.hlog;
-                        if (isFirstBlock) { for (u32 i = (u32)lane; i < cells / 8u; i += ZSA_WAVE) S->filt[i] = 0; }
-                        else {   // the filter mirrors the top 4 bits of every cell
-                            for (u32 i = (u32)lane; i < cells / 8u; i += ZSA_WAVE) {
+                        u32 const fb = P.hlog <= ZSA_FILT_HLOG_MAX ? 4u : 2u, per = 32u / fb;   // filter bits per cell, cells per word
+                        if (isFirstBlock) { for (u32 i = (u32)lane; i < cells / per; i += ZSA_WAVE) S->filt[i] = 0; }
+                        else {   // the filter mirrors the top fb bits of every cell
+                            for (u32 i = (u32)lane; i < cells / per; i += ZSA_WAVE) {
                                 u32 w = 0;
-                                for (u32 k = 0; k < 8; k++) w |= (hashTable[8u * i + k] >> 28) << (4u * k);
+                                for (u32 k = 0; k < per; k++) w |= (hashTable[per * i + k] >> (32u - fb)) << (fb * k);
                                 S->filt[i] = w;
                             }
                         }

@@ -186,13 +186,17 @@ struct ZsaTabGlobal {   // one 32-bit word per cell in the workgroup's global sc
 // the global cell by every store.  `dup` is a bitmap of 1 << hashLog bits, all zero between uses (chunk set-up).
 struct ZsaTabFilt {
     u32* p; u32* filt; u32* dup;
+    u32 fb;            // filter bits per cell: 4 (tables of up to 8192 cells) or 2 (16384 cells) -- the filter is 4 KiB either way
     static constexpr bool filtered = true;
     ZSA_MEM u32 ld(u32 h) const { return wv_ldg_cell(p + h); }
-    ZSA_MEM u32 fget(u32 h) const { return (filt[h >> 3] >> ((h & 7u) * 4u)) & 15u; }
-    // d = old nibble ^ new nibble.  An atomic xor: lanes that update different cells of one word do not disturb each other
-    ZSA_MEM void fxor(u32 h, u32 d) const { (void)wv_atomic_xor_lds(&filt[h >> 3], d << ((h & 7u) * 4u)); }
-    ZSA_MEM void st(u32 h, u32 c) const { wv_stg_cell(p + h, c); u32 const d = fget(h) ^ (c >> 28); if (d) fxor(h, d); }
-    ZSA_MEM u32* dupWord(u32 h) const { return &dup[h >> 5]; }
+    ZSA_MEM u32 top(u32 cell) const { return cell >> (32u - fb); }                 // the bits of a cell that the filter mirrors
+    ZSA_MEM u32 widx(u32 h) const { return fb == 4u ? h >> 3 : h >> 4; }
+    ZSA_MEM u32 wsh(u32 h) const { return fb == 4u ? (h & 7u) * 4u : (h & 15u) * 2u; }
+    ZSA_MEM u32 fget(u32 h) const { return (filt[widx(h)] >> wsh(h)) & ((1u << fb) - 1u); }
+    // d = old bits ^ new bits.  An atomic xor: lanes that update different cells of one word do not disturb each other
+    ZSA_MEM void fxor(u32 h, u32 d) const { (void)wv_atomic_xor_lds(&filt[widx(h)], d << wsh(h)); }
+    ZSA_MEM void st(u32 h, u32 c) const { wv_stg_cell(p + h, c); u32 const d = fget(h) ^ top(c); if (d) fxor(h, d); }
+    ZSA_MEM u32* dupWord(u32 h) const { return &dup[(h >> 5) & 255u]; }             // (cell numbers modulo 8192: a false share only cuts a chunk short)
 };
 
 // One round of match extension for the chunk path: lanes 0..15 compare 8 bytes each forwards from (ip, m) (capped at
@@ -566,9 +570,10 @@ ZSA_DEVFN u32 zsa_ring_fill_far(u8* ringB, const u8* src, u32 hi, u32 want, u32 
 // (written with integer flags and one flat loop on purpose: the loop-carried state then stays in scalar registers and every
 // branch is a scalar compare; booleans carried around a loop turn into 64-bit lane masks)
 template <int MLS>
-ZSA_DEVFN void zsa_parse_chunk(const ZsaTabFilt T, u32* ringWords, const ZsaParseCtx* Cp, ZsaParseState* stp, u32* backoff)
+ZSA_DEVFN void zsa_parse_chunk(const ZsaTabFilt Tin, u32* ringWords, const ZsaParseCtx* Cp, ZsaParseState* stp, u32* backoff)
 {
     int const lane = wv_lane();
+    ZsaTabFilt T = Tin; T.fb = wv_uniform(Tin.fb);          // (arguments of an out-of-line function count as per-lane values)
     ZsaParseCtx const& C = *Cp; ZsaParseState& st = *stp;
     u32 const hlog = wv_uniform(C.hlog), posBits = wv_uniform(C.posBits), iend = wv_uniform(C.iend), ilimit = iend - 8;
     u32 const prefixStartIndex = wv_uniform(C.prefixStartIndex);
@@ -606,11 +611,11 @@ ZSA_DEVFN void zsa_parse_chunk(const ZsaTabFilt T, u32* ringWords, const ZsaPars
             // (== time order), then the (at most two) positions beyond the chunk
             if (winValid) {
                 bool const mine = insV != 0;
-                if (mine && (u32)lane < winValid) { wv_stg_cell(tabP + whash, wcell); u32 const d = wnib ^ (wcell >> 28); if (d) T.fxor(whash, d); }
+                if (mine && (u32)lane < winValid) { wv_stg_cell(tabP + whash, wcell); u32 const d = wnib ^ T.top(wcell); if (d) T.fxor(whash, d); }
                 for (u64 t = wv_ballot(mine && (u32)lane >= winValid); t; t &= t - 1) {
                     wv_lds_fence();
                     ZSA_STAT(7);
-                    if (lane == __builtin_ctzll(t)) { wv_stg_cell(tabP + whash, wcell); u32 const d = T.fget(whash) ^ (wcell >> 28); if (d) T.fxor(whash, d); }
+                    if (lane == __builtin_ctzll(t)) { wv_stg_cell(tabP + whash, wcell); u32 const d = T.fget(whash) ^ T.top(wcell); if (d) T.fxor(whash, d); }
                 }
                 wv_lds_fence();
                 insV = 0;
@@ -621,9 +626,9 @@ ZSA_DEVFN void zsa_parse_chunk(const ZsaTabFilt T, u32* ringWords, const ZsaPars
                 u32 const pp = lane == 0 ? lateA : lateB;
                 u32 hh = 0, cell = 0;
                 if (lane < 2) { u64 const wd = zsa_ring64(R, pp - 2); hh = zsa_hashT<MLS>(wd, hlog); cell = ZSA_CELL(pp, wd); }
-                if (lane == 0 && lateA) { wv_stg_cell(tabP + hh, cell); u32 const d = T.fget(hh) ^ (cell >> 28); if (d) T.fxor(hh, d); }
+                if (lane == 0 && lateA) { wv_stg_cell(tabP + hh, cell); u32 const d = T.fget(hh) ^ T.top(cell); if (d) T.fxor(hh, d); }
                 wv_lds_fence();
-                if (lane == 1) { wv_stg_cell(tabP + hh, cell); u32 const d = T.fget(hh) ^ (cell >> 28); if (d) T.fxor(hh, d); }
+                if (lane == 1) { wv_stg_cell(tabP + hh, cell); u32 const d = T.fget(hh) ^ T.top(cell); if (d) T.fxor(hh, d); }
                 wv_lds_fence();
                 lateA = lateB = 0;
             }
@@ -638,7 +643,7 @@ ZSA_DEVFN void zsa_parse_chunk(const ZsaTabFilt T, u32* ringWords, const ZsaPars
             whash = zsa_hashT<MLS>(wv64, hlog);
             wcell = (ZSA_FPV(wv64) << posBits) | q;
             wnib = T.fget(whash);
-            winH = wv_ballot(wnib == (wcell >> 28));
+            winH = wv_ballot(wnib == T.top(wcell));
             // lanes that share their cell with another lane: the first lane to reach a cell's bit finds it clear, the
             // others find it set and clear it again, which tells the first one
             u32* const dw = T.dupWord(whash);
@@ -810,7 +815,7 @@ ZSA_DEV u32 zsa_parse_fast_blockT(u32* T, u32* filt, u32* dup, u32* ringWords, u
         if (st.rep1 > maxRep) { saved1 = st.rep1; st.rep1 = 0; }
     }
     if (filt) {
-        ZsaTabFilt tab; tab.p = T; tab.filt = filt; tab.dup = dup;
+        ZsaTabFilt tab; tab.p = T; tab.filt = filt; tab.dup = dup; tab.fb = P.hlog <= 13 ? 4u : 2u;
         u32 backoff = 0;
         for (;;) {
             if (st.ip0 >= backoff) zsa_parse_chunk<MLS>(tab, ringWords, &C, &st, &backoff);
