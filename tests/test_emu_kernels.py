@@ -40,6 +40,7 @@ def _inputs():
     out += corpus.frames("log", 131072, 2, 42) + corpus.frames("json", 65536, 2, 1234) + corpus.frames("log", 262144, 1, 43)
     out += corpus.frames("json", 1024, 8, 7) + corpus.frames("log", 12000, 2, 6)
     out.append(rnd.randbytes(131072) + bytes(100000))
+    out += corpus.frames("log", 600000, 1, 44)      # 16384-cell table (2-bit LDS filter), frame longer than the window
     return out
 
 
@@ -169,7 +170,8 @@ def test_emulated_lazy_parse_matches_oracle(emu, oracle):
 def test_emulated_fingerprint_collisions(oracle):
     """zsa_parse.h keeps a fingerprint of the 4 bytes at each position in the spare bits of a match-table cell and only
     reads a candidate's bytes when it wins its window; with 2-bit fingerprints (test build) one probe in four collides,
-    which drives the take-the-next-event path.  Output must not change."""
+    which drives the take-the-next-event path.  Output must not change.  zsa_dfast.h does the same in both of its tables
+    (levels 3 and 4, level 2 at these sizes)."""
     d = os.path.join(ROOT, "tests", "emu")
     subprocess.run(["make", "-s", "-C", d, os.path.join(d, "libzsa_emu_fp2.so")], check=True)
     lib = ctypes.CDLL(os.path.join(d, "libzsa_emu_fp2.so"))
@@ -179,7 +181,7 @@ def test_emulated_fingerprint_collisions(oracle):
     cases = [corpus.frames("log", 40000, 1, 5)[0], corpus.frames("json", 131073, 1, 6)[0], corpus.frames("log", 300000, 1, 7)[0],
              bytes(rnd.choice(b"abcde") for _ in range(30000)) + b"ab" * 3000 + bytes(5000)]
     for data in cases:
-        for level in (1, -3, 2):
+        for level in (1, -3, 2, 3, 4):
             want = oracle.compress(data, level)
             if isinstance(want, int):
                 continue

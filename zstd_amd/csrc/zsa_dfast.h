@@ -19,6 +19,12 @@
 //   * positions up to the event enter both tables in one store each (distinct cells), then the reference's
 //     complementary positions, then the immediate-repcode loop.
 // Match lengths are counted by all lanes, a byte per lane, forwards and backwards in the same round trip.
+//
+// Cells carry a FINGERPRINT above the position (posBits != 0: positions need posBits bits; the long table's from all 8 bytes,
+// the short table's from the 4 bytes its check compares), so equal bytes imply an equal fingerprint and a window decides its
+// probable event from the cells alone -- no round trip for the candidates' bytes.  The bytes are compared where the event is
+// taken: a long match by the extension that measures it anyway, a short match together with the look-ahead's long candidate.
+// A candidate whose fingerprint agreed by accident is struck out and the window's ballot is taken again.
 // Included by zsa_encode.h (uses zsa_hash, zsa_packseq from there).
 #pragma once
 
@@ -63,10 +69,24 @@ ZSA_DEV void zsa_df_extend(const u8* base, u32 ip, u32 m, u32 skip, u32 iend, u3
 // Parses one block.  base: window base (index i <-> base + i).  bmL, bmS: LDS, 512 words each, all zero (left all zero).
 // rep: LDS, [0] and [1] in and out, [2] receives the last literal run.  Returns the number of sequences appended to seqOut.
 // All arguments and the result are wave-uniform.  (A function of its own: its loop gets its own register allocation.)
+// fingerprints: equal 8 (4) bytes give equal values; the top 32 - posBits bits are kept
+ZSA_DEV u32 zsa_df_fpL(u64 v) { return ((u32)v ^ ((u32)(v >> 32) * 2654435761U)) * 2246822519U; }
+ZSA_DEV u32 zsa_df_fpS(u64 v) { return (u32)v * 2246822519U; }
+#ifdef ZSA_FP_TEST_BITS   // test builds: few fingerprint bits, so that accidental agreement is common
+#define ZSA_DF_FP(h) (((h) >> posBits) & ((1u << ZSA_FP_TEST_BITS) - 1u))
+#else
+#define ZSA_DF_FP(h) ((h) >> posBits)
+#endif
+#define ZSA_DF_CELL_L(p, v) (fpOn ? (ZSA_DF_FP(zsa_df_fpL(v)) << posBits) | (p) : (p))
+#define ZSA_DF_CELL_S(p, v) (fpOn ? (ZSA_DF_FP(zsa_df_fpS(v)) << posBits) | (p) : (p))
+
 ZSA_DEVFN u32 zsa_parse_dfast_wave(u32* hashLong, u32* hashSmall, u32 hBitsL, u32 hBitsS, u32 mls, u32 wlog, const u8* base, u32 dictLimit,
-                                   const u8* src, u32 srcSize, u32* rep, u64* seqOut, u32* bmL, u32* bmS)
+                                   const u8* src, u32 srcSize, u32* rep, u64* seqOut, u32* bmL, u32* bmS, u32 posBits)
 {
     int const lane = wv_lane();
+    posBits = wv_uniform(posBits);
+    bool const fpOn = posBits != 0;                                   // (0: plain positions in the cells, candidates' bytes read per window)
+    u32 const posMask = fpOn ? (1u << posBits) - 1u : 0xFFFFFFFFu;
     hashLong = (u32*)wv_uniform64((u64)hashLong); hashSmall = (u32*)wv_uniform64((u64)hashSmall);
     hBitsL = wv_uniform(hBitsL); hBitsS = wv_uniform(hBitsS); mls = wv_uniform(mls); wlog = wv_uniform(wlog);
     base = (const u8*)wv_uniform64((u64)base); dictLimit = wv_uniform(dictLimit);
@@ -107,15 +127,19 @@ ZSA_DEVFN u32 zsa_parse_dfast_wave(u32* hashLong, u32* hashSmall, u32 hBitsL, u3
         bool ends = nEff < nAct;
         bool const probe = (u32)lane <= nEff;                                   // lane nEff: look-ahead, long table only
         bool const both = (u32)lane < nEff;
-        u64 v = 0; u32 hL = 0, hS = 0, iL = 0, iS = 0;
+        u64 v = 0; u32 hL = 0, hS = 0, rawL = 0, rawS = 0;
         if (pvAt != ip0) { pv = wv_ldg64(base + (ip0 + (u32)lane <= ilimit ? ip0 + (u32)lane : ip0)); pvAt = ip0; pvN = ZSA_WAVE; }
         if (probe) {
             v = (cur == ip0 + (u32)lane && (u32)lane < pvN) ? pv : wv_ldg64(base + cur);
             hL = zsa_hash(v, hBitsL, 8);
             hS = zsa_hash(v, hBitsS, mls);
-            iL = wv_ldg_cell(hashLong + hL);
+            rawL = wv_ldg_cell(hashLong + hL);
         }
-        if (both) iS = wv_ldg_cell(hashSmall + hS);
+        if (both) rawS = wv_ldg_cell(hashSmall + hS);
+        u32 cR = wv_ldg32(base + (both ? cur + 1 - off1 : istart));             // the repcode's bytes travel with the cells
+        wv_join(rawL, rawS, cR);
+        u32 const cellL = ZSA_DF_CELL_L(cur, v), cellS = ZSA_DF_CELL_S(cur, v);
+        u32 const iL = rawL & posMask, iS = rawS & posMask;
         u64 sharedL;
         {   // lanes that share a cell with another lane of the window, per table: cut the window below the second-lowest
             u32* const dwL = bmL + ((hL >> 5) & 511u); u32 const bitL = 1u << (hL & 31u);
@@ -142,23 +166,31 @@ ZSA_DEVFN u32 zsa_parse_dfast_wave(u32* hashLong, u32* hashSmall, u32 hBitsL, u3
             if (w < nEff) { nEff = w; ends = false; }                           // (w >= 1)
         }
         bool const mine = (u32)lane < nEff;
-        // candidate bytes of all three checks in one round trip (a lane without a candidate reads its own position)
         bool const hasL = probe && iL > prefixLowest, hasS = mine && iS > prefixLowest;
-        u64 cL = wv_ldg64(base + (hasL ? iL : istart));
-        u32 cS = wv_ldg32(base + (hasS ? iS : istart));
-        u32 cR = wv_ldg32(base + (mine ? cur + 1 - off1 : istart));
-        wv_join(cL, cS, cR);
-        bool const longHit = hasL && cL == v;
-        u32 kind = 0;   // 1: repcode at cur + 1 (:179), 2: long match at cur (:188), 3: short match at cur (:201)
-        if (mine) {
-            if (off1 > 0 && cR == (u32)(v >> 8)) kind = 1;
-            else if (longHit) kind = 2;
-            else if (hasS && cS == (u32)v) kind = 3;
+        // what a lane may hold, in the reference's order: 1: repcode at cur + 1 (:179), 2: long match at cur (:188), 4: short
+        // match at cur (:201).  With fingerprints 2 and 4 are probable until the bytes are compared below.
+        bool longHit; u32 flags = 0;
+        if (fpOn) {
+            longHit = hasL && (rawL >> posBits) == ZSA_DF_FP(zsa_df_fpL(v));
+            if (hasS && (rawS >> posBits) == ZSA_DF_FP(zsa_df_fpS(v))) flags = 4;
+        } else {   // candidates' bytes in one more round trip (a lane without a candidate reads its own block's start)
+            u64 cL = wv_ldg64(base + (hasL ? iL : istart));
+            u32 cS = wv_ldg32(base + (hasS ? iS : istart)), c3 = 0;
+            wv_join(cL, cS, c3);
+            longHit = hasL && cL == v;
+            if (hasS && cS == (u32)v) flags = 4;
         }
-        u64 const found = wv_ballot(kind != 0);
-        u32 const nIns = found ? (u32)__builtin_ctzll(found) + 1 : nEff;        // positions that enter the tables (:174)
-        if ((u32)lane < nIns) { wv_stg_cell(hashLong + hL, cur); wv_stg_cell(hashSmall + hS, cur); }   // (distinct cells: the window was cut)
-        wv_lds_fence();
+        if (longHit) flags |= 2;
+        if (off1 > 0 && cR == (u32)(v >> 8)) flags |= 1;
+        if (!mine) flags = 0;
+        u32 nStored = 0;                                                        // positions of this window already in the tables
+      again: ;
+        u64 const found = wv_ballot(flags != 0);
+        {   u32 const nIns = found ? (u32)__builtin_ctzll(found) + 1 : nEff;    // positions that enter the tables (:174) -- at least these
+            if ((u32)lane >= nStored && (u32)lane < nIns) { wv_stg_cell(hashLong + hL, cellL); wv_stg_cell(hashSmall + hS, cellS); }   // (distinct cells: the window was cut)
+            wv_lds_fence();
+            nStored = nIns;
+        }
         if (!found) {
             if (ends) break;
             // the step after the last position of the window (:208-223)
@@ -177,33 +209,47 @@ ZSA_DEVFN u32 zsa_parse_dfast_wave(u32* hashLong, u32* hashSmall, u32 hBitsL, u3
             continue;
         }
         int const e = __builtin_ctzll(found);
-        u32 const eKind = wv_readlane(kind, e), curE = ip0 + (u32)e;
+        u32 const eFlags = wv_readlane(flags, e), curE = ip0 + (u32)e;
         u32 const eStep = (u32)e == nAct - 1 ? lastStep : 1u;                   // `step` as the reference holds it at this position
         u32 const ip1 = wv_readlane(cur, e + 1), hl1 = wv_readlane(hL, e + 1);
         u32 start, mLength, offBase;
-        if (eKind == 1) {
+        if (eFlags & 1) {
             start = curE + 1;
             mLength = zsa_df_count(base, start + 4, start + 4 - off1, iend, lane) + 4;
             offBase = 1;
         } else {
             u32 ipM = curE, m, skip;
-            if (eKind == 2) { m = wv_readlane(iL, e); skip = 8; }
+            if (eFlags & 2) { m = wv_readlane(iL, e); skip = fpOn ? 0 : 8; }    // (with fingerprints the extension compares the first 8 bytes too)
             else {   // _search_next_long (:237-253): a long match at ip1 beats the short one at ip
-                u32 iL1; bool hit1;
-                if (!((sharedL >> (e + 1)) & 1)) { iL1 = wv_readlane(iL, e + 1); hit1 = wv_readlane(longHit ? 1u : 0u, e + 1) != 0; }
+                u32 raw1; bool prob1;
+                if (!((sharedL >> (e + 1)) & 1)) { raw1 = wv_readlane(rawL, e + 1); prob1 = wv_readlane(longHit ? 1u : 0u, e + 1) != 0; }
                 else {   // that lane's probe may predate a store of this window: read the cell again
-                    iL1 = wv_uniform(wv_ldg_cell(hashLong + hl1));
-                    u64 const v1 = (u64)wv_readlane((u32)v, e + 1) | ((u64)wv_readlane((u32)(v >> 32), e + 1) << 32);
-                    hit1 = iL1 > prefixLowest && wv_uniform64(wv_ldg64(base + (iL1 > prefixLowest ? iL1 : istart))) == v1;
+                    raw1 = wv_uniform(wv_ldg_cell(hashLong + hl1));
+                    prob1 = (raw1 & posMask) > prefixLowest && (!fpOn || (raw1 >> posBits) == (wv_readlane(cellL, e + 1) >> posBits));
                 }
-                if (hit1) { ipM = ip1; m = iL1; skip = 8; } else { m = wv_readlane(iS, e); skip = 4; }
+                u32 const iL1 = raw1 & posMask, mS = wv_readlane(iS, e);
+                bool hit1 = prob1, shortOk = true;
+                if (fpOn || ((sharedL >> (e + 1)) & 1)) {   // the bytes of the short candidate and of the look-ahead's long one, one round trip
+                    u64 const v1 = (u64)wv_readlane((u32)v, e + 1) | ((u64)wv_readlane((u32)(v >> 32), e + 1) << 32);
+                    u64 c1 = wv_ldg64(base + (prob1 ? iL1 : istart));
+                    u32 c4 = wv_ldg32(base + mS), c3 = 0;
+                    wv_join(c1, c4, c3);
+                    hit1 = prob1 && wv_uniform64(c1) == v1;
+                    shortOk = wv_uniform(c4) == wv_readlane((u32)v, e);
+                }
+                if (!shortOk) { if (lane == e) flags &= ~4u; goto again; }      // (fingerprints only) not a match: the reference moves on
+                if (hit1) { ipM = ip1; m = iL1; skip = 8; } else { m = mS; skip = 4; }
             }
             u32 fwd, bwd;
             zsa_df_extend(base, ipM, m, skip, iend, anchor, prefixLowest, &fwd, &bwd, lane);
+            if (skip == 0) {
+                if (fwd < 8) { if (lane == e) flags &= ~2u; goto again; }       // the long candidate's fingerprint agreed by accident
+            }
             start = ipM - bwd;
             mLength = skip + fwd + bwd;
             off2 = off1; off1 = ipM - m;                                        // _match_found (:257-259)
-            if (eStep < 4 && lane == 0) wv_stg_cell(hashLong + hl1, ip1);       // :261-266
+            u32 const cell1 = wv_readlane(cellL, e + 1);
+            if (eStep < 4 && lane == 0) wv_stg_cell(hashLong + hl1, cell1);     // :261-266
             wv_lds_fence();
             offBase = off1 + 3;
         }
@@ -222,17 +268,19 @@ ZSA_DEVFN u32 zsa_parse_dfast_wave(u32* hashLong, u32* hashSmall, u32 hBitsL, u3
             wv_join(pv, r2, r3);
             u32 const hl = zsa_hash(w, hBitsL, 8);
             u32 const hs = zsa_hash(lane == 1 ? w >> 8 : w, hBitsS, mls);       // lane 1: the bytes at ip - 1 (mls <= 7)
-            if (lane == 0) { wv_stg_cell(hashLong + hl, pp); wv_stg_cell(hashSmall + hs, pp); }
+            u32 const cl = ZSA_DF_CELL_L(pp, w);
+            if (lane == 0) { wv_stg_cell(hashLong + hl, cl); wv_stg_cell(hashSmall + hs, ZSA_DF_CELL_S(pp, w)); }
             wv_lds_fence();
-            if (lane == 1) { wv_stg_cell(hashLong + hl, pp); wv_stg_cell(hashSmall + hs, pp + 1); }
+            if (lane == 1) { wv_stg_cell(hashLong + hl, cl); wv_stg_cell(hashSmall + hs, ZSA_DF_CELL_S(pp + 1, w >> 8)); }
             wv_lds_fence();
             u32 vi = wv_readlane((u32)w, 2), ri = wv_readlane(r2, 2);
             u32 hli = wv_readlane(hl, 2), hsi = wv_readlane(hs, 2);
+            u32 cli = wv_readlane(cl, 2), csi = wv_readlane(ZSA_DF_CELL_S(pp, w), 2);
             while ((off2 > 0) & (vi == ri)) {   // immediate repcode (:290-302); ip0 <= ilimit holds
                 u32 const rLength = zsa_df_count(base, ip0 + 4, ip0 + 4 - off2, iend, lane) + 4;
                 { u32 const t = off2; off2 = off1; off1 = t; }
                 if (lane == 0) {
-                    wv_stg_cell(hashSmall + hsi, ip0); wv_stg_cell(hashLong + hli, ip0);
+                    wv_stg_cell(hashSmall + hsi, csi); wv_stg_cell(hashLong + hli, cli);
                     wv_stg64(seqOut + nbSeq, zsa_packseq(0, rLength - ZSA_MINMATCH, 1));
                 }
                 wv_lds_fence();
@@ -246,6 +294,7 @@ ZSA_DEVFN u32 zsa_parse_dfast_wave(u32* hashLong, u32* hashSmall, u32 hBitsL, u3
                 u64 const wi = (u64)wv_readlane((u32)pv, 0) | ((u64)wv_readlane((u32)(pv >> 32), 0) << 32);
                 vi = (u32)wi; ri = wv_uniform(ri);
                 hli = zsa_hash(wi, hBitsL, 8); hsi = zsa_hash(wi, hBitsS, mls);
+                cli = ZSA_DF_CELL_L(ip0, wi); csi = ZSA_DF_CELL_S(ip0, wi);
             }
         }
         step = 1; nextStep = ip0 + 256;                                         // :157-158 a new search
@@ -256,3 +305,6 @@ ZSA_DEVFN u32 zsa_parse_dfast_wave(u32* hashLong, u32* hashSmall, u32 hBitsL, u3
     if (lane == 0) { rep[0] = off1 ? off1 : saved1; rep[1] = off2 ? off2 : saved2; rep[2] = iend - anchor; }
     return wv_uniform(nbSeq);
 }
+#undef ZSA_DF_CELL_L
+#undef ZSA_DF_FP
+#undef ZSA_DF_CELL_S

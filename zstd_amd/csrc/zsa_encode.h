@@ -1402,6 +1402,9 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
     u32 fpPosBits = 0;
     if (!cd && P.strat == 1) { u32 const bits = 32u - (u32)__builtin_clz(srcSize + 2u); if (bits <= 26u) fpPosBits = bits; }
     // chunk path (zsa_parse.h): levels 1-2 (step 2) with a table the LDS filter covers
+    // ZSTD_dfast cells carry fingerprints as well (zsa_dfast.h) while the frame's positions leave at least 6 bits for them
+    u32 dfPosBits = 0;
+    if (FAMILY == 3) { u32 const bits = 32u - (u32)__builtin_clz(srcSize + 2u); if (bits <= 26u) dfPosBits = bits; }
     bool const chunkParse = FAMILY == 2 && fpPosBits != 0 && P.tlen <= 1 && P.hlog <= ZSA_FILT_HLOG_MAX + 1;
     int const literalsDisabled = (P.strat == 1) && (P.tlen > 0);   // zstd_compress_internal.h:605-618
     u32 const maxDist = 1u << P.wlog;
@@ -1493,7 +1496,7 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
                     if (lane == 0) { io[0] = rep[0]; io[1] = rep[1]; io[2] = 0; }
                     wv_sync();
                     nbSeq = wv_uniform(zsa_parse_dfast_wave(hashTable, hashTable + (1u << P.hlog), P.hlog, P.clog, P.mml, P.wlog, Wn.base, Wn.dictLimit,
-                                                            ip, blockSize, io, W.seq, S->filt, S->filt + 512));
+                                                            ip, blockSize, io, W.seq, S->filt, S->filt + 512, dfPosBits));
                     wv_sync();
                     rep[0] = io[0]; rep[1] = io[1]; lastLL = io[2];
                 } else {   // ZSTD_fast without a dictionary segment: the wave parser (zsa_parse.h)
