@@ -401,7 +401,7 @@ def main():
         }
         if not args.no_end_to_end:
             try:
-                res["end_to_end"] = end_to_end(zstd_amd, host, FS, min(N, 2048), args.level)
+                res["end_to_end"] = end_to_end(zstd_amd, host, FS, min(N, 4096), args.level)
             except Exception as e:   # a reported extra, never a reason to lose the line
                 res["end_to_end"] = {"failed": repr(e)}
         if not args.no_cpu_baseline:

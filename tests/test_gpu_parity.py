@@ -307,6 +307,33 @@ def test_bulk_small_payload_batch(z, oracle):
     assert sum(map(len, got)) < 0.45 * 1024 * 4096
 
 
+def test_large_host_batch_staged_by_helper_threads(z, oracle):
+    # host batches above 8 MiB are staged piece by piece by helper threads and their compressed output is packed on the
+    # device before it travels back (zsa_lib.hip: zsa_run_host_batch); ragged sizes, empty payloads, incompressible ones
+    # (output fills its capacity: no packing), a failing frame in the middle
+    import random
+    from zstd_amd import corpus
+    rnd = random.Random(77)
+    frames = corpus.frames("log", 131072, 90, 901) + corpus.frames("json", 50000, 40, 902)
+    frames += [b"", b"x", rnd.randbytes(70000), bytes(200000)] + [f[:rnd.randrange(1, 60000)] for f in corpus.frames("log", 60000, 30, 903)]
+    rnd.shuffle(frames)
+    assert sum(map(len, frames)) > (12 << 20)
+    got = z.CompressBatch(frames, 1)
+    for i in range(0, len(frames), 7):
+        assert got[i] == oracle.compress(frames[i], 1), i
+    assert z.DecompressBatch(got, [len(f) for f in frames]) == frames
+    caps = [len(f) for f in frames]
+    bad = next(i for i, f in enumerate(frames) if len(f) > 1000)
+    caps[bad] -= 1                                             # destination one byte short: that frame alone fails
+    back = z.DecompressBatch(got, caps)
+    assert isinstance(back[bad], z.ErrorCode)
+    assert all(b == f for i, (b, f) in enumerate(zip(back, frames)) if i != bad)
+    rand = [rnd.randbytes(131072) for _ in range(80)]          # nothing to pack: output as large as the capacities
+    out = z.CompressBatch(rand, 1)
+    assert out[3] == oracle.compress(rand[3], 1)
+    assert z.DecompressBatch(out, [131072] * 80) == rand
+
+
 def test_dfast_levels_match_golden(z, oracle):
     """levels 3 and 4 (and 2 at <= 256 KB, 0 = default) -- strategy ZSTD_dfast -- byte-identical to the
     reference-generated fixture, multi-block frames included (1 MiB at level 3 is BASELINE config 5's chunk)"""

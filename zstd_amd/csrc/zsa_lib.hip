@@ -4,7 +4,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <vector>
 #include "zsa_common.h"
 #include "zsa_params.h"
@@ -550,7 +552,8 @@ static bool g_zsaExiting = false;
 static void zsa_mark_exit() { g_zsaExiting = true; }
 struct ZsaStage {
     u8 *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr;
-    size_t inCap = 0, outCap = 0;
+    u64 *h_meta = nullptr, *d_meta = nullptr;   // per frame (offset in d_out, packed offset, size): large batches only
+    size_t inCap = 0, outCap = 0, metaCap = 0;
     zsa_batch* batch = nullptr;
     hipStream_t stream = nullptr;
     int device = -1;
@@ -558,9 +561,10 @@ struct ZsaStage {
     {
         if (h_in) { (void)hipHostFree(h_in); (void)hipFree(d_in); }
         if (h_out) { (void)hipHostFree(h_out); (void)hipFree(d_out); }
+        if (h_meta) { (void)hipHostFree(h_meta); (void)hipFree(d_meta); }
         if (batch) zsa_batch_free(batch);
         if (stream) (void)hipStreamDestroy(stream);
-        h_in = h_out = d_in = d_out = nullptr; inCap = outCap = 0; batch = nullptr; stream = nullptr;
+        h_in = h_out = d_in = d_out = nullptr; h_meta = d_meta = nullptr; inCap = outCap = metaCap = 0; batch = nullptr; stream = nullptr;
     }
     ~ZsaStage()
     {
@@ -577,7 +581,7 @@ static thread_local ZsaStage t_stage;
 // freed by ZSTD_freeCCtx/ZSTD_freeDCtx: zstd_ctx.go:43-51).
 extern "C" void zsa_thread_release(void) { if (t_stage.device != -1) { t_stage.release(); t_stage.device = -1; } }
 
-static size_t zsa_stage_reserve(ZsaStage& st, size_t inBytes, size_t outBytes, size_t nFrames)
+static size_t zsa_stage_reserve(ZsaStage& st, size_t inBytes, size_t outBytes, size_t nFrames, size_t metaBytes)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { fprintf(stderr, "libzstd_amd: no usable HIP device -- this library has no CPU path\n"); return kErrGeneric; }
@@ -585,7 +589,7 @@ static size_t zsa_stage_reserve(ZsaStage& st, size_t inBytes, size_t outBytes, s
         if (st.device != -1) {   // (what it holds belongs to the old device)
             int const old = st.device;
             if (hipSetDevice(old) == hipSuccess) { st.release(); (void)hipSetDevice(dev); }
-            else { st.h_in = st.h_out = st.d_in = st.d_out = nullptr; st.inCap = st.outCap = 0; st.batch = nullptr; st.stream = nullptr; }
+            else { st.h_in = st.h_out = st.d_in = st.d_out = nullptr; st.h_meta = st.d_meta = nullptr; st.inCap = st.outCap = st.metaCap = 0; st.batch = nullptr; st.stream = nullptr; }
         }
         static std::once_flag once;
         std::call_once(once, [] { atexit(zsa_mark_exit); });
@@ -604,6 +608,12 @@ static size_t zsa_stage_reserve(ZsaStage& st, size_t inBytes, size_t outBytes, s
         if (hipHostMalloc((void**)&st.h_out, cap, hipHostMallocDefault) != hipSuccess || hipMalloc((void**)&st.d_out, cap) != hipSuccess) return kErrMemory;
         st.outCap = cap;
     }
+    if (metaBytes > st.metaCap) {
+        if (st.h_meta) { (void)hipHostFree(st.h_meta); (void)hipFree(st.d_meta); st.h_meta = st.d_meta = nullptr; st.metaCap = 0; }
+        size_t const cap = metaBytes + (metaBytes >> 2) + 4096;
+        if (hipHostMalloc((void**)&st.h_meta, cap, hipHostMallocDefault) != hipSuccess || hipMalloc((void**)&st.d_meta, cap) != hipSuccess) return kErrMemory;
+        st.metaCap = cap;
+    }
     if (!st.batch || st.batch->maxFrames < nFrames) {
         if (st.batch) zsa_batch_free(st.batch);
         size_t const cap = nFrames + (nFrames >> 2);   // sized to the request, geometric growth: a thread that compresses one
@@ -613,34 +623,149 @@ static size_t zsa_stage_reserve(ZsaStage& st, size_t inBytes, size_t outBytes, s
     return 0;
 }
 
+// ---- large host batches: the copies between the caller's (pageable) buffers and the pinned staging buffers are what a
+// host batch spends most of its time on, so from ZSA_PAR_MIN_BYTES on they are made by a few helper threads, piece by
+// piece, while the pieces already staged cross PCIe; compressed output is packed on the device first, so that only the
+// bytes produced travel back.  Helper threads make no HIP calls.  ZSTD_AMD_COPY_THREADS (default 4, 1 = none) sets their number.
+#define ZSA_PAR_MIN_BYTES ((size_t)8 << 20)
+static unsigned zsa_copy_threads()
+{
+    static unsigned const conf = [] { const char* e = getenv("ZSTD_AMD_COPY_THREADS"); int const v = e ? atoi(e) : 4; return (unsigned)(v < 1 ? 1 : (v > 16 ? 16 : v)); }();
+    return conf;
+}
+// frames [0, n) cut into pieces of about equal staged size: piece p = frames [cut[p], cut[p + 1])
+static std::vector<size_t> zsa_cut_pieces(const std::vector<size_t>& off, size_t total, size_t n, size_t pieces)
+{
+    std::vector<size_t> cut; cut.push_back(0);
+    for (size_t p = 1; p < pieces; p++) {
+        size_t const want = total / pieces * p;
+        size_t f = cut.back();
+        while (f < n && off[f] < want) f++;
+        if (f > cut.back() && f < n) cut.push_back(f);
+    }
+    cut.push_back(n);
+    return cut;
+}
+// Runs copyFrame(i) for every frame of every piece on `threads` helper threads: helper w takes pieces w, w + threads, ...; a
+// piece is started once ready(p) has returned (called on the helper) and reported through done(p) (called on the caller's
+// thread, in piece order, as soon as the piece is complete).
+struct ZsaPieceFlags {
+    std::vector<std::atomic<int>> f;
+    explicit ZsaPieceFlags(size_t n) : f(n) { for (auto& x : f) x.store(0, std::memory_order_relaxed); }
+    void set(size_t p) { f[p].store(1, std::memory_order_release); }
+    void wait(size_t p) { unsigned spins = 0; while (!f[p].load(std::memory_order_acquire)) { if (++spins > 64) std::this_thread::yield(); } }
+};
+
+// packs the produced bytes of every frame back to back (16-byte aligned offsets): one workgroup per frame
+__global__ void __launch_bounds__(256) zsa_k_pack(const u8* __restrict__ from, u8* __restrict__ to, const u64* __restrict__ meta, u32 n)
+{
+    u32 const i = blockIdx.x;
+    if (i >= n) return;
+    u64 const srcOff = meta[3 * (size_t)i], dstOff = meta[3 * (size_t)i + 1], size = meta[3 * (size_t)i + 2];
+    const uint4* const a = (const uint4*)(from + srcOff);
+    uint4* const b = (uint4*)(to + dstOff);
+    u64 const q = size >> 4;
+    for (u64 k = threadIdx.x; k < q; k += 256) b[k] = a[k];
+    for (u64 k = (q << 4) + threadIdx.x; k < size; k += 256) to[dstOff + k] = from[srcOff + k];
+}
+
 static size_t zsa_run_host_batch(bool compress, const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCapacity,
                                  size_t* outSize, size_t n, int level, const zsa_CDict* cd, const zsa_DDict* dd)
 {
     if (n == 0) return 0;
     ZsaStage& st = t_stage;
     // layout: inputs and outputs packed back to back, 16-byte aligned, with 32 bytes of slack after each input
-    std::vector<size_t> inOff(n), outOff(n);
+    std::vector<size_t> inOff(n + 1), outOff(n + 1);
     size_t inBytes = 0, outBytes = 0;
     for (size_t i = 0; i < n; i++) {
         inOff[i] = inBytes; inBytes += (srcSize[i] + 32 + 15) & ~(size_t)15;
         outOff[i] = outBytes; outBytes += (dstCapacity[i] + 15) & ~(size_t)15;
     }
-    { size_t const e = zsa_stage_reserve(st, inBytes, outBytes, n); if (e) return e; }
-    for (size_t i = 0; i < n; i++) {
-        if (srcSize[i]) memcpy(st.h_in + inOff[i], src[i], srcSize[i]);
-        zsa_batch_set_frame(st.batch, i, st.d_in + inOff[i], srcSize[i], st.d_out + outOff[i], dstCapacity[i]);
+    inOff[n] = inBytes; outOff[n] = outBytes;
+    unsigned const T = (n >= 8 && inBytes + outBytes >= ZSA_PAR_MIN_BYTES) ? zsa_copy_threads() : 1;
+    { size_t const e = zsa_stage_reserve(st, inBytes, outBytes, n, T > 1 ? 3 * n * sizeof(u64) : 0); if (e) return e; }
+    for (size_t i = 0; i < n; i++) zsa_batch_set_frame(st.batch, i, st.d_in + inOff[i], srcSize[i], st.d_out + outOff[i], dstCapacity[i]);
+    if (T == 1) {
+        for (size_t i = 0; i < n; i++) if (srcSize[i]) memcpy(st.h_in + inOff[i], src[i], srcSize[i]);
+        HIPCHK(hipMemcpyAsync(st.d_in, st.h_in, inBytes, hipMemcpyHostToDevice, st.stream));
+    } else {   // helpers stage piece after piece; each piece crosses PCIe while the next ones are being staged
+        std::vector<size_t> const cut = zsa_cut_pieces(inOff, inBytes, n, (size_t)T * 4);
+        size_t const P = cut.size() - 1;
+        ZsaPieceFlags staged(P);
+        std::vector<std::thread> helpers;
+        u8* const h_in = st.h_in;
+        for (unsigned w = 0; w < T; w++) helpers.emplace_back([&, w] {
+            for (size_t p = w; p < P; p += T) {
+                for (size_t i = cut[p]; i < cut[p + 1]; i++) if (srcSize[i]) memcpy(h_in + inOff[i], src[i], srcSize[i]);
+                staged.set(p);
+            }
+        });
+        hipError_t err = hipSuccess;
+        for (size_t p = 0; p < P; p++) {
+            staged.wait(p);
+            size_t const lo = inOff[cut[p]], hi = inOff[cut[p + 1]];
+            if (err == hipSuccess && hi > lo) err = hipMemcpyAsync(st.d_in + lo, st.h_in + lo, hi - lo, hipMemcpyHostToDevice, st.stream);
+        }
+        for (auto& h : helpers) h.join();
+        HIPCHK(err);
     }
-    HIPCHK(hipMemcpyAsync(st.d_in, st.h_in, inBytes, hipMemcpyHostToDevice, st.stream));
     { size_t const e = zsa_batch_upload(st.batch, n, st.stream); if (e) return e; }
     { size_t const e = compress ? zsa_compress_enqueue(st.batch, level, cd, st.stream) : zsa_decompress_enqueue(st.batch, dd, st.stream); if (e) return e; }
     { size_t const e = zsa_batch_results(st.batch, outSize, st.stream); if (e) return e; }
     // copy back only what was produced
-    size_t lo = (size_t)-1, hi = 0;
-    for (size_t i = 0; i < n; i++) if (!zsa_isError(outSize[i]) && outSize[i]) { if (outOff[i] < lo) lo = outOff[i]; if (outOff[i] + outSize[i] > hi) hi = outOff[i] + outSize[i]; }
-    if (hi > lo) {
+    size_t lo = (size_t)-1, hi = 0, produced = 0;
+    for (size_t i = 0; i < n; i++) if (!zsa_isError(outSize[i]) && outSize[i]) {
+        if (outOff[i] < lo) lo = outOff[i];
+        if (outOff[i] + outSize[i] > hi) hi = outOff[i] + outSize[i];
+        produced += (outSize[i] + 15) & ~(size_t)15;
+    }
+    if (hi <= lo) return 0;
+    if (T == 1) {
         HIPCHK(hipMemcpyAsync(st.h_out + lo, st.d_out + lo, hi - lo, hipMemcpyDeviceToHost, st.stream));
         HIPCHK(hipStreamSynchronize(st.stream));
         for (size_t i = 0; i < n; i++) if (!zsa_isError(outSize[i]) && outSize[i]) memcpy(dst[i], st.h_out + outOff[i], outSize[i]);
+        return 0;
+    }
+    // Where the frames filled less than three quarters of their capacities (compressed output), the produced bytes are first
+    // packed into the input staging buffer on the device -- its content is no longer needed -- and travel from there.
+    std::vector<size_t> hostOff(n + 1);
+    const u8* d_from = st.d_out; u8* h_to = st.h_out;
+    bool const pack = n <= 0xFFFFFFFFu && produced <= st.inCap && produced < (hi - lo) / 4 * 3;
+    if (pack) {
+        size_t at = 0;
+        for (size_t i = 0; i < n; i++) {
+            size_t const sz = (!zsa_isError(outSize[i])) ? outSize[i] : 0;
+            hostOff[i] = at; st.h_meta[3 * i] = outOff[i]; st.h_meta[3 * i + 1] = at; st.h_meta[3 * i + 2] = sz;
+            at += (sz + 15) & ~(size_t)15;
+        }
+        hostOff[n] = at;
+        HIPCHK(hipMemcpyAsync(st.d_meta, st.h_meta, 3 * n * sizeof(u64), hipMemcpyHostToDevice, st.stream));
+        hipLaunchKernelGGL(zsa_k_pack, dim3((unsigned)n), dim3(256), 0, st.stream, (const u8*)st.d_out, st.d_in, (const u64*)st.d_meta, (u32)n);
+        HIPCHK(hipGetLastError());
+        d_from = st.d_in; h_to = st.h_in;
+    } else {
+        for (size_t i = 0; i <= n; i++) hostOff[i] = outOff[i];
+    }
+    {   std::vector<size_t> const cut = zsa_cut_pieces(hostOff, hostOff[n], n, (size_t)T * 4);
+        size_t const P = cut.size() - 1;
+        ZsaPieceFlags arrived(P);
+        std::vector<std::thread> helpers;
+        for (unsigned w = 0; w < T; w++) helpers.emplace_back([&, w] {
+            for (size_t p = w; p < P; p += T) {
+                arrived.wait(p);
+                if (arrived.f[p].load(std::memory_order_acquire) < 0) continue;   // (the transfer failed: nothing to hand out)
+                for (size_t i = cut[p]; i < cut[p + 1]; i++) if (!zsa_isError(outSize[i]) && outSize[i]) memcpy(dst[i], h_to + hostOff[i], outSize[i]);
+            }
+        });
+        hipError_t err = hipSuccess;
+        for (size_t p = 0; p < P; p++) {
+            size_t const a = hostOff[cut[p]], b = hostOff[cut[p + 1]];
+            if (err == hipSuccess && b > a) err = hipMemcpyAsync(h_to + a, d_from + a, b - a, hipMemcpyDeviceToHost, st.stream);
+            if (err == hipSuccess) err = hipStreamSynchronize(st.stream);
+            arrived.f[p].store(err == hipSuccess ? 1 : -1, std::memory_order_release);
+        }
+        for (auto& h : helpers) h.join();
+        HIPCHK(err);
     }
     return 0;
 }
