@@ -8,8 +8,8 @@
  * Scope of the engine: compression at the levels whose strategy is ZSTD_fast (level 1 and the negative levels at every
  * size, level 2 above 256 KB and up to 128 KB), ZSTD_dfast (levels 3 and 0 at every size, level 4 except at <= 16 KB
  * and in (128 KB, 256 KB], level 2 in (128 KB, 256 KB]) or ZSTD_greedy / ZSTD_lazy / ZSTD_lazy2 (level 5 -- the default of
- * the reference's Compress(), zstd.go:23 -- at every size; levels 4 to 12 wherever clevels.h selects one of the three, as
- * long as the frame's match tables fit the 5 MiB a resident workgroup owns), byte-identical to libzstd 1.5.5;
+ * the reference's Compress(), zstd.go:23 -- at every size; levels 4 to 12 wherever clevels.h selects one of the three),
+ * byte-identical to libzstd 1.5.5;
  * dictionary compression (CDict) at the ZSTD_fast levels; decompression of any
  * Zstandard frame (concatenated and skippable frames, checksums, dictionaries) except legacy v0.x frames.
  * Anything else returns an error code -- there is no CPU fallback inside this library: every entry point

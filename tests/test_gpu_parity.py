@@ -408,6 +408,30 @@ def test_lazy_levels_match_golden(z, oracle):
                 assert z.Decompress(None, c) == f
 
 
+def test_high_levels_on_large_inputs(z, oracle):
+    # levels 9-12 on inputs above 512 KiB: ZSTD_lazy2 with tables of 8-21 MiB per frame in flight (round 1 refused these);
+    # the launch is sized to what its frames need
+    from zstd_amd import corpus
+    frames = [corpus.frames("log", 600000, 1, 61)[0], corpus.frames("json", 1100000, 1, 62)[0], corpus.frames("log", 3000, 1, 63)[0]]
+    for level in (9, 10, 12):
+        got = z.CompressBatch(frames, level)
+        assert got[0] == oracle.compress(frames[0], level) and got[1] == oracle.compress(frames[1], level), level
+        # (at 3000 bytes these levels are ZSTD_btlazy2: outside the engine, and the oracle says the same)
+        assert isinstance(got[2], z.ErrorCode) and str(got[2]) == "Unsupported parameter" and oracle.compress(frames[2], level) == -40
+        assert z.DecompressBatch(got[:2], [len(f) for f in frames[:2]]) == frames[:2]
+
+
+def test_frames_longer_than_the_window(z, oracle):
+    # 3 and 5 MB frames: longer than the window of every level used here (512 KiB .. 4 MiB), 24-39 blocks each
+    from zstd_amd import corpus
+    frames = [corpus.frames("log", 3000000, 1, 71)[0], corpus.frames("json", 5000000, 1, 72)[0]]
+    for level in (1, 3, 5, 12):
+        got = z.CompressBatch(frames, level)
+        for f, c in zip(frames, got):
+            assert c == oracle.compress(f, level), (len(f), level)
+        assert z.DecompressBatch(got, [len(f) for f in frames]) == frames
+
+
 def test_ctx_go_cases(z, oracle):
     # zstd_ctx_test.go:9-40 (round trip, Decompress with a too-small dst), :42-66 (levels), :75-119 (empty input / output),
     # :121-142 (130 KB payload into a short dst)

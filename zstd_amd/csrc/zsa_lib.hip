@@ -25,11 +25,13 @@
 #define ZSA_ENC_WAVES 4       // waves per SIMD the compress kernel is register-budgeted for (16 workgroups per CU)
 #endif
 #ifndef ZSA_HT_BYTES
-#define ZSA_HT_BYTES   ((size_t)5 << 20)                     // match table(s) of the frame in flight: 4 << hashLog bytes, plus
+#define ZSA_HT_BYTES   ((size_t)48 << 20)                    // match table(s) of the frame in flight: 4 << hashLog bytes, plus
                                                             // 4 << chainLog for ZSTD_dfast (level 4 at > 256 KB: 1 MiB + 1 MiB), the
                                                             // hash chain or the row finder's tags for greedy/lazy/lazy2 (levels 7-8
-                                                            // at > 256 KB: 4 MiB + 1 MiB)
+                                                            // at > 256 KB: 4 MiB + 1 MiB; level 12 at >= 4 MiB: 32 MiB + 8 MiB).  A
+                                                            // launch is sized to what its frames need, not to this ceiling
 #endif
+#define ZSA_HT_BYTES_UNSIZED ((size_t)5 << 20)               // ... when the frames' sizes are known on the device only
 #define ZSA_PARK_BYTES ((3 * sizeof(ZsaFseCT) + 255) / 256 * 256)   // sequence tables of the last compressed block (ZSTD_lazy and up)
 // Compression workspace of one resident workgroup, sized from the launch: `blockCap` = largest block of the batch (<= 128 KiB),
 // `htBytes` = largest match-table footprint any of its frames needs.  [seq | lit | tmp | park | tables]
@@ -396,7 +398,7 @@ static void zsa_plan_compress(zsa_batch* b, int level, const zsa_CDict* cdict)
 {
     if (b->planValid && b->planLevel == level && b->planDict == (const void*)cdict) return;
     b->planLevel = level; b->planDict = cdict; b->planValid = true; b->planHtBytes = 4096;
-    if (b->sizesOnDevice) { b->planHtBytes = ZSA_HT_BYTES; return; }   // sizes unknown here: the largest tables the workgroup arena may hold
+    if (b->sizesOnDevice) { b->planHtBytes = ZSA_HT_BYTES_UNSIZED; return; }   // sizes unknown here: a fixed arena (larger tables are refused per frame)
     for (size_t i = 0; i < b->nFrames; i++) {
         ZsaCParams cp; int dictMode = zsa_dm_none;
         u64 const n = b->h_frames[i].srcSize;
@@ -415,7 +417,15 @@ extern "C" size_t zsa_compress_enqueue(zsa_batch* b, int level, const zsa_CDict*
     zsa_plan_compress(b, level, cdict);
     ZsaEncLayout const L = zsa_enc_layout(b->sizesOnDevice ? ZSA_BLOCKSIZE_MAX : b->maxSrcSize, b->planHtBytes);
     size_t const ldsPerWG = sizeof(ZsaEncShared) + 64;
-    unsigned const grid = zsa_grid(b, ldsPerWG);
+    unsigned grid = zsa_grid(b, ldsPerWG);
+    if (L.stride > ((u64)8 << 20) && (size_t)grid * L.stride > b->encScratchBytes) {
+        // large tables (high levels on large inputs): the workspace of a full grid may not fit; the launch then keeps
+        // fewer frames in flight -- at most half of what the device has free
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) { (void)hipGetLastError(); freeB = 0; }
+        size_t const budget = (freeB + b->encScratchBytes) / 2;
+        if ((size_t)grid * L.stride > budget) { size_t const g = budget / L.stride; grid = (unsigned)(g ? g : 1); }
+    }
     {   // workspace: grows when a launch needs more than the batch has held so far; steady-state enqueues allocate nothing
         size_t const need = (size_t)grid * L.stride;
         if (need > b->encScratchBytes) {
