@@ -39,8 +39,13 @@ def run(name, kind, fs, n, seed, level, dictionary=None, steps=3):
         want = orc.compress_cdict(f, ocd) if ocd else orc.compress(f, level)
         assert ch[i * stride:i * stride + csz[i]].tobytes() == want, "frame %d differs from the oracle" % i
     tot = float(n) * fs
-    print("%-46s %7.2f GB/s compress %7.2f GB/s decompress  ratio %.3f  (%d x %d B, level %d%s; sample byte-identical, round trip exact)"
-          % (name, tot / (tc / steps) / 1e6, tot / (td / steps) / 1e6, tot / sum(csz), n, fs, level, ", dictionary %d B" % len(dictionary) if dictionary else ""), flush=True)
+    # roofline of each launch as bench.py states it: algorithmic bytes (input + output of the launch) / time against 8 TB/s of HBM
+    alg = tot + float(sum(csz))
+    kern = "zsa_k_compress_dict" if dictionary is not None else ("zsa_k_compress" if level < 3 else ("zsa_k_compress_dfast" if level < 5 else "zsa_k_compress_lazy"))
+    print("%-46s %7.2f GB/s compress %7.2f GB/s decompress  ratio %.3f  (%d x %d B, level %d%s; sample byte-identical, round trip exact)\n"
+          "%-46s roofline (hbm, 8000 GB/s): %s %.1f GB/s = %.2f %%, zsa_k_decompress %.1f GB/s = %.2f %%"
+          % (name, tot / (tc / steps) / 1e6, tot / (td / steps) / 1e6, tot / sum(csz), n, fs, level, ", dictionary %d B" % len(dictionary) if dictionary else "",
+             "", kern, alg / (tc / steps) / 1e6, alg / (tc / steps) / 1e6 / 80.0, alg / (td / steps) / 1e6, alg / (td / steps) / 1e6 / 80.0), flush=True)
     del src, cbuf, out, enc, dec
     torch.cuda.empty_cache()
 

@@ -471,45 +471,73 @@ ZSA_DEV void zsa_huf_quickSort(ZsaHufNode* a, int low0, int high0)
         } else sp--;
     }
 }
-// huf_compress.c:596-641 HUF_sort
-ZSA_DEV void zsa_huf_sort(ZsaEncShared* S, ZsaHufNode* node, const u32* count, u32 maxSV)
+// HUF_sort (huf_compress.c:596-641) by the whole wave.  The reference drops the symbols into buckets (counts below 166: one
+// bucket per count; above: one per power of two), buckets in descending order and symbols in ascending order inside a bucket,
+// and then sorts the buckets of large counts with its quick sort.  Here lane l owns symbols l, l + 64, l + 128, l + 192; a
+// symbol's slot is the number of symbols whose key (bucket, 255 - symbol) is larger, counted against the keys of all lanes
+// (readlane, no memory), and lane 0 then runs the quick sort over each large-count bucket with more than one member -- its
+// order among equal counts is part of the format's byte identity, so that step is kept move for move.
+// Returns the rank of the last symbol with a non-zero count.
+ZSA_DEV u32 zsa_huf_sort_wave(ZsaHufNode* node, const u32* count, u32 maxSV, int lane)
 {
     u32 const maxSV1 = maxSV + 1;
-    for (u32 n = 0; n < 192; n++) { S->rpBase[n] = 0; S->rpCurr[n] = 0; }
-    for (u32 n = 0; n < maxSV1; ++n) S->rpBase[zsa_huf_bucket(count[n])]++;
-    for (u32 n = 191; n > 0; --n) { S->rpBase[n - 1] += S->rpBase[n]; S->rpCurr[n - 1] = S->rpBase[n - 1]; }
-    for (u32 n = 0; n < maxSV1; ++n) {
-        u32 const c = count[n], r = zsa_huf_bucket(c) + 1, pos = S->rpCurr[r]++;
-        node[pos].count = c; node[pos].byte = (u8)n;
+    u32 key[4], cnt[4], pos[4];
+    for (u32 k = 0; k < 4; k++) {
+        u32 const n = (u32)lane + 64u * k;
+        cnt[k] = n < maxSV1 ? count[n] : 0u;
+        key[k] = n < maxSV1 ? ((zsa_huf_bucket(cnt[k]) + 1u) << 8) | (255u - n) : 0u;   // (0: not a symbol, sorts last)
+        pos[k] = 0;
     }
-    for (u32 n = 166; n < 191; ++n) {
-        int const bucketSize = (int)S->rpCurr[n] - (int)S->rpBase[n];
-        if (bucketSize > 1) zsa_huf_quickSort(node + S->rpBase[n], 0, bucketSize - 1);
+    for (u32 g = 0; g < 4 && 64u * g < maxSV1; g++) {
+        u32 const lim = maxSV1 - 64u * g < 64u ? maxSV1 - 64u * g : 64u;
+        for (u32 j = 0; j < lim; j++) {
+            u32 const other = wv_readlane(key[g], (int)j);
+            for (u32 k = 0; k < 4; k++) pos[k] += other > key[k] ? 1u : 0u;
+        }
     }
+    for (u32 k = 0; k < 4; k++) if (key[k]) { node[pos[k]].count = cnt[k]; node[pos[k]].byte = (u8)((u32)lane + 64u * k); }
+    u32 nonNull = 0;
+    for (u32 k = 0; k < 4; k++) nonNull += (u32)__builtin_popcountll(wv_ballot(cnt[k] != 0));
+    wv_sync();
+    // the buckets of large counts, largest first: [start, start + size)
+    // (bucket 165 holds the counts 165 .. 255, 166 the counts 256 .. 511, ...: huf_compress.c:630-638 sorts from there up)
+    u32 start = 0;
+    for (u32 b = 190; b >= 165; b--) {
+        u32 size = 0;
+        for (u32 k = 0; k < 4; k++) size += (u32)__builtin_popcountll(wv_ballot((key[k] >> 8) == b + 1u));
+        if (size > 1 && lane == 0) zsa_huf_quickSort(node + start, 0, (int)size - 1);
+        start += size;
+    }
+    wv_sync();
+    return nonNull - 1;
 }
-// huf_compress.c:657-694 HUF_buildTree
-ZSA_DEV int zsa_huf_buildTree(ZsaHufNode* node, u32 maxSV)
+// HUF_buildTree (huf_compress.c:657-694): the two-queue merge is one dependency chain (lane 0); the sentinels before it and the
+// leaves' depths after it are set by all lanes.
+ZSA_DEV void zsa_huf_buildTree_wave(ZsaHufNode* node, u32 nonNullRank, int lane)
 {
     ZsaHufNode* const node0 = node - 1;
-    int nonNullRank = (int)maxSV, lowS, lowN, nodeNb = 256, nodeRoot;
-    while (node[nonNullRank].count == 0) nonNullRank--;
-    lowS = nonNullRank; nodeRoot = nodeNb + lowS - 1; lowN = nodeNb;
-    node[nodeNb].count = node[lowS].count + node[lowS - 1].count;
-    node[lowS].parent = node[lowS - 1].parent = (u16)nodeNb;
-    nodeNb++; lowS -= 2;
-    for (int n = nodeNb; n <= nodeRoot; n++) node[n].count = 1u << 30;
-    node0[0].count = 1u << 31;
-    while (nodeNb <= nodeRoot) {
-        int const n1 = (node[lowS].count < node[lowN].count) ? lowS-- : lowN++;
-        int const n2 = (node[lowS].count < node[lowN].count) ? lowS-- : lowN++;
-        node[nodeNb].count = node[n1].count + node[n2].count;
-        node[n1].parent = node[n2].parent = (u16)nodeNb;
-        nodeNb++;
+    int const nodeRoot = 256 + (int)nonNullRank - 1;
+    for (int n = 257 + lane; n <= nodeRoot; n += ZSA_WAVE) node[n].count = 1u << 30;
+    if (lane == 0) node0[0].count = 1u << 31;
+    wv_sync();
+    if (lane == 0) {
+        int lowS = (int)nonNullRank, lowN = 256, nodeNb = 256;
+        node[nodeNb].count = node[lowS].count + node[lowS - 1].count;
+        node[lowS].parent = node[lowS - 1].parent = (u16)nodeNb;
+        nodeNb++; lowS -= 2;
+        while (nodeNb <= nodeRoot) {
+            int const n1 = (node[lowS].count < node[lowN].count) ? lowS-- : lowN++;
+            int const n2 = (node[lowS].count < node[lowN].count) ? lowS-- : lowN++;
+            node[nodeNb].count = node[n1].count + node[n2].count;
+            node[n1].parent = node[n2].parent = (u16)nodeNb;
+            nodeNb++;
+        }
+        node[nodeRoot].nbBits = 0;
+        for (int n = nodeRoot - 1; n >= 256; n--) node[n].nbBits = node[node[n].parent].nbBits + 1;
     }
-    node[nodeRoot].nbBits = 0;
-    for (int n = nodeRoot - 1; n >= 256; n--) node[n].nbBits = node[node[n].parent].nbBits + 1;
-    for (int n = 0; n <= nonNullRank; n++) node[n].nbBits = node[node[n].parent].nbBits + 1;
-    return nonNullRank;
+    wv_sync();
+    for (int n = lane; n <= (int)nonNullRank; n += ZSA_WAVE) node[n].nbBits = node[node[n].parent].nbBits + 1;
+    wv_sync();
 }
 // huf_compress.c:352-474 HUF_setMaxHeight
 ZSA_DEV u32 zsa_huf_setMaxHeight(ZsaHufNode* node, u32 lastNonNull, u32 targetNbBits)
@@ -568,24 +596,52 @@ ZSA_DEV u32 zsa_huf_setMaxHeight(ZsaHufNode* node, u32 lastNonNull, u32 targetNb
     }
     return targetNbBits;
 }
-// huf_compress.c:730-766 HUF_buildCTable_wksp + :706-728; returns maxNbBits (0 on error)
-ZSA_DEV u32 zsa_huf_buildCTable(ZsaEncShared* S, ZsaHufCT* ct, const u32* count, u32 maxSV, u32 maxNbBits)
+// HUF_buildCTable_wksp (huf_compress.c:730-766 + :706-728) by all lanes; returns maxNbBits (0 on error), uniform.
+// Code values: symbols of one length take consecutive values in symbol order -- the rank of a symbol among the symbols of its
+// length is a ballot per length over 64 symbols at a time.
+ZSA_DEV u32 zsa_huf_buildCTable_wave(ZsaEncShared* S, ZsaHufCT* ct, const u32* count, u32 maxSV, u32 maxNbBits, int lane)
 {
     ZsaHufNode* const node = S->node + 1;
-    for (u32 i = 0; i < 2 * 256 + 2; i++) { S->node[i].count = 0; S->node[i].parent = 0; S->node[i].byte = 0; S->node[i].nbBits = 0; }
-    zsa_huf_sort(S, node, count, maxSV);
-    int const nonNullRank = zsa_huf_buildTree(node, maxSV);
-    maxNbBits = zsa_huf_setMaxHeight(node, (u32)nonNullRank, maxNbBits);
+    for (u32 i = (u32)lane; i < 2 * 256 + 2; i += ZSA_WAVE) { S->node[i].count = 0; S->node[i].parent = 0; S->node[i].byte = 0; S->node[i].nbBits = 0; }
+    wv_sync();
+    u32 const nonNullRank = zsa_huf_sort_wave(node, count, maxSV, lane);
+    zsa_huf_buildTree_wave(node, nonNullRank, lane);
+    if (lane == 0) S->u[EU_s0] = zsa_huf_setMaxHeight(node, nonNullRank, maxNbBits);
+    wv_sync();
+    maxNbBits = S->u[EU_s0];
     if (maxNbBits > ZSA_HUF_TABLELOG_MAX) return 0;
-    u16 nbPerRank[ZSA_HUF_TABLELOG_MAX + 1], valPerRank[ZSA_HUF_TABLELOG_MAX + 1];
-    for (u32 i = 0; i <= ZSA_HUF_TABLELOG_MAX; i++) { nbPerRank[i] = 0; valPerRank[i] = 0; }
-    for (int n = 0; n <= nonNullRank; n++) nbPerRank[node[n].nbBits]++;
-    {   u16 min = 0;
-        for (int n = (int)maxNbBits; n > 0; n--) { valPerRank[n] = min; min += nbPerRank[n]; min >>= 1; }
+    for (u32 i = (u32)lane; i < 256; i += ZSA_WAVE) { ct->nbBits[i] = 0; ct->val[i] = 0; }
+    wv_sync();
+    for (u32 n = (u32)lane; n <= maxSV; n += ZSA_WAVE) ct->nbBits[node[n].byte] = node[n].nbBits;
+    wv_sync();
+    // first value per length (:712-722): from the number of symbols of each length among ranks 0 .. nonNullRank
+    u32 nb[4];
+    for (u32 k = 0; k < 4; k++) { u32 const n = (u32)lane + 64u * k; nb[k] = n <= maxSV ? ct->nbBits[n] : 0xFFu; }
+    u32 valPerRank[ZSA_HUF_TABLELOG_MAX + 1];
+    {   u32 perRank[ZSA_HUF_TABLELOG_MAX + 1];
+        for (u32 b = 0; b <= ZSA_HUF_TABLELOG_MAX; b++) {
+            u32 c = 0;
+            if (b) for (u32 k = 0; k < 4; k++) c += (u32)__builtin_popcountll(wv_ballot(nb[k] == b));   // (symbols of length b all have a count: they lie below nonNullRank)
+            perRank[b] = c;
+        }
+        u32 min = 0;   // (the reference's U16 arithmetic)
+        valPerRank[0] = 0;
+        for (u32 n = ZSA_HUF_TABLELOG_MAX; n > 0; n--) {
+            valPerRank[n] = 0;
+            if (n <= maxNbBits) { valPerRank[n] = min & 0xFFFFu; min = ((min + perRank[n]) & 0xFFFFu) >> 1; }
+        }
     }
-    for (u32 n = 0; n < 256; n++) { ct->nbBits[n] = 0; ct->val[n] = 0; }
-    for (u32 n = 0; n <= maxSV; n++) ct->nbBits[node[n].byte] = node[n].nbBits;
-    for (u32 n = 0; n <= maxSV; n++) { u32 const b = ct->nbBits[n]; u16 const v = valPerRank[b]++; ct->val[n] = b ? v : 0; }
+    for (u32 k = 0; k < 4; k++) {
+        u32 v = 0;
+        for (u32 b = 1; b <= ZSA_HUF_TABLELOG_MAX; b++) {   // (no symbol is longer than maxNbBits)
+            u64 const m = wv_ballot(nb[k] == b);
+            if (nb[k] == b) v = valPerRank[b] + (u32)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+            valPerRank[b] += (u32)__builtin_popcountll(m);
+        }
+        u32 const n = (u32)lane + 64u * k;
+        if (n <= maxSV) ct->val[n] = (u16)v;
+    }
+    wv_sync();
     return maxNbBits;
 }
 // huf_compress.c:147-187 HUF_compressWeights; returns size; 0 "not compressible", 1 "rle", 0xFFFFFFFF error
@@ -638,29 +694,35 @@ ZSA_DEV u32 zsa_huf_compressWeights(ZsaEncShared* S, u8* dst, const u8* weights,
     }
     return (u32)(op - dst);
 }
-// huf_compress.c:230-268 HUF_writeCTable_wksp; returns header size, 0 on error
-ZSA_DEV u32 zsa_huf_writeCTable(ZsaEncShared* S, u8* dst, const ZsaHufCT* ct, u32 maxSV, u32 huffLog)
+// huf_compress.c:230-268 HUF_writeCTable_wksp; returns header size, 0 on error (uniform).  The weights are derived by all
+// lanes; their FSE compression (a few dozen symbols of an alphabet of 13) is one short chain on lane 0.
+ZSA_DEV u32 zsa_huf_writeCTable(ZsaEncShared* S, u8* dst, const ZsaHufCT* ct, u32 maxSV, u32 huffLog, int lane)
 {
-    u8 bitsToWeight[ZSA_HUF_TABLELOG_MAX + 1];
     u8* const huffWeight = S->huffWeight;
-    bitsToWeight[0] = 0;
-    for (u32 n = 1; n < huffLog + 1; n++) bitsToWeight[n] = (u8)(huffLog + 1 - n);
-    for (u32 n = 0; n < maxSV; n++) huffWeight[n] = bitsToWeight[ct->nbBits[n]];
-    {   u32 const hSize = zsa_huf_compressWeights(S, dst + 1, huffWeight, maxSV);
-        if (hSize == 0xFFFFFFFFu) return 0;
-        if ((hSize > 1) & (hSize < maxSV / 2)) { dst[0] = (u8)hSize; return hSize + 1; }
+    for (u32 n = (u32)lane; n < maxSV; n += ZSA_WAVE) { u32 const b = ct->nbBits[n]; huffWeight[n] = (u8)(b ? huffLog + 1 - b : 0); }
+    wv_sync();
+    if (lane == 0) {
+        u32 r;
+        u32 const hSize = zsa_huf_compressWeights(S, dst + 1, huffWeight, maxSV);
+        if (hSize == 0xFFFFFFFFu) r = 0;
+        else if ((hSize > 1) & (hSize < maxSV / 2)) { dst[0] = (u8)hSize; r = hSize + 1; }
+        else if (maxSV > (256 - 128)) r = 0;
+        else {
+            dst[0] = (u8)(128 + (maxSV - 1));
+            huffWeight[maxSV] = 0;
+            for (u32 n = 0; n < maxSV; n += 2) dst[(n / 2) + 1] = (u8)((huffWeight[n] << 4) + huffWeight[n + 1]);
+            r = ((maxSV + 1) / 2) + 1;
+        }
+        S->u[EU_s0] = r;
     }
-    if (maxSV > (256 - 128)) return 0;
-    dst[0] = (u8)(128 + (maxSV - 1));
-    huffWeight[maxSV] = 0;
-    for (u32 n = 0; n < maxSV; n += 2) dst[(n / 2) + 1] = (u8)((huffWeight[n] << 4) + huffWeight[n + 1]);
-    return ((maxSV + 1) / 2) + 1;
+    wv_sync();
+    return S->u[EU_s0];
 }
-ZSA_DEV u32 zsa_huf_estimate(const ZsaHufCT* ct, const u32* count, u32 maxSV)
-{   // huf_compress.c:768-777
-    u64 nbBits = 0;
-    for (u32 s = 0; s <= maxSV; ++s) nbBits += (u64)ct->nbBits[s] * count[s];
-    return (u32)(nbBits >> 3);
+ZSA_DEV u32 zsa_huf_estimate(const ZsaHufCT* ct, const u32* count, u32 maxSV, int lane)
+{   // huf_compress.c:768-777 (a wave sum; a block's literals are at most 128 KiB, so the bit count fits 32 bits)
+    u32 nbBits = 0;
+    for (u32 s = (u32)lane; s <= maxSV; s += ZSA_WAVE) nbBits += (u32)ct->nbBits[s] * count[s];
+    return wv_reduce_add(nbBits) >> 3;
 }
 // one Huffman stream, symbols last -> first, end mark (huf_compress.c:1023-1086, :941-950); run by one lane
 ZSA_DEV u32 zsa_huf_encode1X(u8* dst, const u8* src, u32 srcSize, const ZsaHufCT* ct)
@@ -791,26 +853,26 @@ ZSA_DEV u32 zsa_compressLiterals(ZsaEncShared* S, u8* dst, const u8* lit, u32 li
         else if (largest <= (litSize >> 7) + 4) decision = 0;
     }
     if (decision == 0xFF) {
-        if (lane == 0) {
+        {   // (all lanes, uniform)
             u32 repeat = prevRepeat, dec = 3, hSize = 0;
             if (repeat == zsa_rep_check) {   // HUF_validateCTable (:779-787)
-                u32 bad = 0;
-                for (u32 s = 0; s <= maxSV; ++s) bad |= (S->count[s] != 0) & (S->hufPrev.nbBits[s] == 0);
-                if (bad) repeat = zsa_rep_none;
+                bool bad = false;
+                for (u32 s = (u32)lane; s <= maxSV; s += ZSA_WAVE) bad |= (S->count[s] != 0) & (S->hufPrev.nbBits[s] == 0);
+                if (wv_ballot(bad)) repeat = zsa_rep_none;
             }
             if (preferRepeat && repeat != zsa_rep_none) dec = 2;
             else {
                 u32 huffLog = zsa_fse_optimalTableLog(11, litSize, maxSV, 1);
-                u32 const maxBits = zsa_huf_buildCTable(S, &S->hufNext, S->count, maxSV, huffLog);
+                u32 const maxBits = zsa_huf_buildCTable_wave(S, &S->hufNext, S->count, maxSV, huffLog, lane);
                 if (maxBits == 0) dec = 0;   // error -> literals stored raw (zstd_compress_literals.c:189)
                 else {
                     huffLog = maxBits;
-                    hSize = zsa_huf_writeCTable(S, ostart, &S->hufNext, maxSV, huffLog);
+                    hSize = zsa_huf_writeCTable(S, ostart, &S->hufNext, maxSV, huffLog, lane);
                     if (hSize == 0) dec = 0;
                     else {
                         if (repeat != zsa_rep_none) {
-                            u32 const oldSize = zsa_huf_estimate(&S->hufPrev, S->count, maxSV);
-                            u32 const newSize = zsa_huf_estimate(&S->hufNext, S->count, maxSV);
+                            u32 const oldSize = zsa_huf_estimate(&S->hufPrev, S->count, maxSV, lane);
+                            u32 const newSize = zsa_huf_estimate(&S->hufNext, S->count, maxSV, lane);
                             if (oldSize <= hSize + newSize || hSize + 12 >= litSize) dec = 2;
                         }
                         if (dec == 3 && hSize + 12 >= litSize) dec = 0;
@@ -818,7 +880,8 @@ ZSA_DEV u32 zsa_compressLiterals(ZsaEncShared* S, u8* dst, const u8* lit, u32 li
                     }
                 }
             }
-            S->u[EU_useOld] = dec; S->u[EU_hSize] = (dec == 3) ? hSize : 0; S->u[EU_tmp] = repeat;
+            wv_sync();
+            if (lane == 0) { S->u[EU_useOld] = dec; S->u[EU_hSize] = (dec == 3) ? hSize : 0; S->u[EU_tmp] = repeat; }
         }
         wv_sync();
         decision = S->u[EU_useOld];

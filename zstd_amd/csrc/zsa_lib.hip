@@ -704,12 +704,15 @@ static size_t zsa_run_host_batch(bool compress, const void* const* src, const si
         ZsaPieceFlags staged(P);
         std::vector<std::thread> helpers;
         u8* const h_in = st.h_in;
-        for (unsigned w = 0; w < T; w++) helpers.emplace_back([&, w] {
+        auto const work = [&](unsigned w) {
             for (size_t p = w; p < P; p += T) {
                 for (size_t i = cut[p]; i < cut[p + 1]; i++) if (srcSize[i]) memcpy(h_in + inOff[i], src[i], srcSize[i]);
                 staged.set(p);
             }
-        });
+        };
+        unsigned made = 0;
+        try { for (; made < T; made++) helpers.emplace_back(work, made); } catch (...) { }
+        for (unsigned w = made; w < T; w++) work(w);   // (a helper that could not be started: its share is copied here)
         hipError_t err = hipSuccess;
         for (size_t p = 0; p < P; p++) {
             staged.wait(p);
@@ -721,7 +724,14 @@ static size_t zsa_run_host_batch(bool compress, const void* const* src, const si
     }
     { size_t const e = zsa_batch_upload(st.batch, n, st.stream); if (e) return e; }
     { size_t const e = compress ? zsa_compress_enqueue(st.batch, level, cd, st.stream) : zsa_decompress_enqueue(st.batch, dd, st.stream); if (e) return e; }
+    // small calls (the one-shot entry points): the whole output region travels back with the result words, one wait for both
+    bool const eager = outBytes <= ((size_t)256 << 10);
+    if (eager) HIPCHK(hipMemcpyAsync(st.h_out, st.d_out, outBytes, hipMemcpyDeviceToHost, st.stream));
     { size_t const e = zsa_batch_results(st.batch, outSize, st.stream); if (e) return e; }
+    if (eager) {
+        for (size_t i = 0; i < n; i++) if (!zsa_isError(outSize[i]) && outSize[i]) memcpy(dst[i], st.h_out + outOff[i], outSize[i]);
+        return 0;
+    }
     // copy back only what was produced
     size_t lo = (size_t)-1, hi = 0, produced = 0;
     for (size_t i = 0; i < n; i++) if (!zsa_isError(outSize[i]) && outSize[i]) {
@@ -760,13 +770,15 @@ static size_t zsa_run_host_batch(bool compress, const void* const* src, const si
         size_t const P = cut.size() - 1;
         ZsaPieceFlags arrived(P);
         std::vector<std::thread> helpers;
-        for (unsigned w = 0; w < T; w++) helpers.emplace_back([&, w] {
+        auto const work = [&](unsigned w) {
             for (size_t p = w; p < P; p += T) {
                 arrived.wait(p);
                 if (arrived.f[p].load(std::memory_order_acquire) < 0) continue;   // (the transfer failed: nothing to hand out)
                 for (size_t i = cut[p]; i < cut[p + 1]; i++) if (!zsa_isError(outSize[i]) && outSize[i]) memcpy(dst[i], h_to + hostOff[i], outSize[i]);
             }
-        });
+        };
+        unsigned made = 0;
+        try { for (; made < T; made++) helpers.emplace_back(work, made); } catch (...) { }
         hipError_t err = hipSuccess;
         for (size_t p = 0; p < P; p++) {
             size_t const a = hostOff[cut[p]], b = hostOff[cut[p + 1]];
@@ -774,6 +786,7 @@ static size_t zsa_run_host_batch(bool compress, const void* const* src, const si
             if (err == hipSuccess) err = hipStreamSynchronize(st.stream);
             arrived.f[p].store(err == hipSuccess ? 1 : -1, std::memory_order_release);
         }
+        for (unsigned w = made; w < T; w++) work(w);   // (a helper that could not be started: its share is handed out here)
         for (auto& h : helpers) h.join();
         HIPCHK(err);
     }
