@@ -310,36 +310,138 @@ ZSA_DEV u32 zsa_huf_readStats(ZsaDecShared* S, u32* nbSymbolsPtr, u32* tableLogP
     return iSize + 1;
 }
 
-// huf_decompress.c:358-492 HUF_readDTableX1_wksp: lane 0 reads the description and assigns every symbol
-// its first cell; all lanes then fill the table.  Returns header size (uniform), 0 on error (S->err set).
+// The weights' FSE stream (fse_decompress.c:177-237 FSE_decompress_usingDTable_generic, at most 255 weights): two interleaved
+// states, one chain -- lane 0.  Table: S->fseCell.  Returns the number of weights, 0 on error.
+ZSA_DEV u32 zsa_huf_decodeWeights(ZsaDecShared* S, const u8* cSrc, u32 cSrcSize, u32 tableLog)
+{
+    u8* const huffWeight = S->weights;
+    ZsaBitR bitD;
+    if (zsa_br_init(bitD, cSrc, cSrcSize)) return 0;
+    u32 state1 = zsa_br_read(bitD, tableLog); zsa_br_reload(bitD);
+    u32 state2 = zsa_br_read(bitD, tableLog); zsa_br_reload(bitD);
+    u32 op = 0;
+    u32 const omax = 255;
+#define ZSA_FSE_GET(st) do { u32 const c = S->fseCell[st]; huffWeight[op++] = (u8)(c >> 16); st = (c & 0xFFFF) + zsa_br_read(bitD, c >> 24); } while (0)
+    while ((zsa_br_reload(bitD) == ZB_unfinished) & (op + 3 < omax)) {
+        ZSA_FSE_GET(state1); ZSA_FSE_GET(state2); ZSA_FSE_GET(state1); ZSA_FSE_GET(state2);
+    }
+    for (;;) {
+        if (op + 2 > omax) return 0;
+        ZSA_FSE_GET(state1);
+        if (zsa_br_reload(bitD) == ZB_overflow) { ZSA_FSE_GET(state2); break; }
+        if (op + 2 > omax) return 0;
+        ZSA_FSE_GET(state2);
+        if (zsa_br_reload(bitD) == ZB_overflow) { ZSA_FSE_GET(state1); break; }
+    }
+#undef ZSA_FSE_GET
+    return op;
+}
+
+// HUF_readStats + HUF_readDTableX1_wksp (entropy_common.c:244-307, huf_decompress.c:358-492) by the whole wave.  Lane 0 reads the
+// first byte and, for FSE-compressed weights, the table description and -- once all lanes have laid out that table
+// (zsa_fse_spread_wave) -- the weight stream, which is one chain.  Everything after the weights is data-parallel, lane l
+// owning symbols l, l + 64, l + 128, l + 192: the number of symbols per weight is a ballot per weight, a symbol's first cell is
+// its weight's first cell plus its rank among the symbols of that weight (symbol order, again ballots), and the table is filled by
+// each lane for its own short symbols and by all lanes together for the long ones (64 cells and more).
+// Returns header size (uniform), 0 on error (S->err set; every failure reads as "corruption detected", zstd_decompress_block.c:224).
 ZSA_DEV u32 zsa_huf_buildTable(ZsaDecShared* S, const u8* src, u32 srcSize, int lane)
 {
-    if (lane == 0) {
-        u32 nbSymbols = 0, tableLog = 0, err = 0;
-        u32 const h = zsa_huf_readStats(S, &nbSymbols, &tableLog, src, srcSize, &err);
-        if (!err) {
-            u32 next = 0, rankStart[ZSA_HUF_TABLELOG_MAX + 2];
-            for (u32 w = 1; w <= tableLog; w++) { rankStart[w] = next; next += S->rankVal[w] << (w - 1); }
-            for (u32 n = 0; n < nbSymbols; n++) {
-                u32 const w = S->weights[n];
-                if (w) { S->symStart[n] = (u16)rankStart[w]; rankStart[w] += (1u << w) >> 1; }
+    u8* const huffWeight = S->weights;
+    u32 mode = 0, iSize = 0, oSize = 0, wLog = 0, wMax = 0, nc = 0;   // mode 0: error, 1: 4-bit weights, 2: FSE, 3: done by lane 0 alone
+    if (lane == 0 && srcSize) {
+        iSize = src[0];
+        if (iSize >= 128) {
+            oSize = iSize - 127; iSize = (oSize + 1) / 2;
+            if (iSize + 1 <= srcSize) mode = 1;                  // (oSize <= 128)
+        } else if (iSize + 1 <= srcSize) {
+            u32 e = 0; wMax = 255;
+            nc = zsa_readNCount(S->norm, &wMax, &wLog, src + 1, iSize, &e);
+            if (!e && wLog <= 6) mode = 2;
+        }
+    }
+    mode = wv_readlane(mode, 0); iSize = wv_readlane(iSize, 0); oSize = wv_readlane(oSize, 0);
+    wLog = wv_readlane(wLog, 0); wMax = wv_readlane(wMax, 0); nc = wv_readlane(nc, 0);
+    wv_sync();
+    if (mode == 1) {
+        if (2u * (u32)lane < oSize) { u32 const b = src[1 + lane]; huffWeight[2 * lane] = (u8)(b >> 4); huffWeight[2 * lane + 1] = (u8)(b & 15); }
+    } else if (mode == 2) {
+        if (wMax > 63) {   // more weight values than a valid description can hold: the serial routine decides (and fails later)
+            u32 n = 0, tl = 0, h = 0;
+            if (lane == 0) { u32 e = 0; h = zsa_huf_readStats(S, &n, &tl, src, srcSize, &e); if (e) n = 0; (void)h; }
+            oSize = wv_readlane(n, 0);
+            mode = oSize ? 3 : 0;
+            if (oSize) oSize -= 1;                               // (readStats counts the implied last symbol)
+        } else {
+            u32 const tableSize = 1u << wLog;
+            ZsaSpreadScratch X; X.first = S->symbolNext; X.seen = S->symbolNext + 64; X.sym = (u8*)S->symStart;
+            zsa_fse_spread_wave(X, S->norm, wMax, wLog, lane, [&](u32 u, u32 symbol, u32 rank) {
+                int const n = S->norm[symbol];
+                u32 const nextState = (n == -1 ? 1u : (u32)n) + rank;
+                u32 const nbBits = wLog - zsa_highbit32(nextState);
+                S->fseCell[u] = (((nextState << nbBits) - tableSize) & 0xFFFF) | (symbol << 16) | (nbBits << 24);
+            });
+            wv_sync();
+            u32 n = 0;
+            if (lane == 0) n = zsa_huf_decodeWeights(S, src + 1 + nc, iSize - nc, wLog);
+            oSize = wv_readlane(n, 0);
+            if (!oSize) mode = 0;
+        }
+    }
+    wv_sync();
+    // weights -> symbols per weight, table log, the implied last weight (entropy_common.c:285-305)
+    u32 w[4];
+    bool tooLarge = false;
+    for (u32 k = 0; k < 4; k++) { u32 const n = (u32)lane + 64u * k; w[k] = (mode && n < oSize) ? huffWeight[n] : 0u; tooLarge |= w[k] > ZSA_HUF_TABLELOG_MAX; }
+    if (wv_ballot(tooLarge)) mode = 0;
+    u32 perWeight[ZSA_HUF_TABLELOG_MAX + 1], weightTotal = 0;
+    for (u32 t = 1; t <= ZSA_HUF_TABLELOG_MAX; t++) {
+        u32 c = 0;
+        for (u32 k = 0; k < 4; k++) c += (u32)__builtin_popcountll(wv_ballot(w[k] == t));
+        perWeight[t] = c; weightTotal += c << (t - 1);
+    }
+    u32 tableLog = 0, lastWeight = 0;
+    if (mode && weightTotal) {
+        tableLog = zsa_highbit32(weightTotal) + 1;
+        u32 const rest = (1u << tableLog) - weightTotal;
+        lastWeight = zsa_highbit32(rest) + 1;
+        if (tableLog > ZSA_HUF_TABLELOG_MAX || (1u << zsa_highbit32(rest)) != rest) mode = 0;
+    } else mode = 0;
+    for (u32 t = 1; t <= ZSA_HUF_TABLELOG_MAX; t++) perWeight[t] += (t == lastWeight) ? 1u : 0u;
+    if (mode && ((perWeight[1] < 2) || (perWeight[1] & 1))) mode = 0;
+    if (!mode) {
+        if (lane == 0) S->err = ZSA_corruption_detected;
+        wv_sync();
+        return 0;
+    }
+    u32 const nbSymbols = oSize + 1;
+    for (u32 k = 0; k < 4; k++) if ((u32)lane + 64u * k == oSize) w[k] = lastWeight;
+    if (lane == 0) S->hufLog = tableLog;
+    // first cell of every symbol (huf_decompress.c:398-436: symbols sorted by weight, symbol order kept inside a weight)
+    u32 first[4] = { 0, 0, 0, 0 };
+    {   u32 next = 0, rankStart[ZSA_HUF_TABLELOG_MAX + 1];
+        for (u32 t = 1; t <= ZSA_HUF_TABLELOG_MAX; t++) { rankStart[t] = next; next += perWeight[t] << (t - 1); }
+        for (u32 k = 0; k < 4; k++)
+            for (u32 t = 1; t <= ZSA_HUF_TABLELOG_MAX; t++) {
+                u64 const m = wv_ballot(w[k] == t);
+                if (w[k] == t) first[k] = rankStart[t] + ((u32)__builtin_popcountll(m & ((1ull << lane) - 1ull)) << (t - 1));
+                rankStart[t] += (u32)__builtin_popcountll(m) << (t - 1);
             }
-            S->hufLog = tableLog;
-        } else S->err = ZSA_corruption_detected;   // zstd_decompress_block.c:224
-        S->u[ZU_tmp] = h; S->u[ZU_hufOff] = nbSymbols;
+    }
+    // fill: symbols of fewer than 64 cells by their lane, the others by all lanes
+    for (u32 k = 0; k < 4; k++) {
+        u32 const n = (u32)lane + 64u * k;
+        u32 const len = w[k] ? (1u << w[k]) >> 1 : 0u;
+        u32 const cell = ((tableLog + 1 - w[k]) << 8) | n;
+        if (len && len < ZSA_WAVE) for (u32 u = 0; u < len; u++) S->huf[first[k] + u] = (u16)cell;
+        for (u64 big = wv_ballot(len >= ZSA_WAVE); big; big &= big - 1) {
+            int const j = __builtin_ctzll(big);
+            u32 const l2 = wv_readlane(len, j), f2 = wv_readlane(first[k], j), c2 = wv_readlane(cell, j);
+            for (u32 u = (u32)lane; u < l2; u += ZSA_WAVE) S->huf[f2 + u] = (u16)c2;
+        }
     }
     wv_sync();
-    if (S->err) return 0;
-    u32 const nbSymbols = S->u[ZU_hufOff], tableLog = S->hufLog;
-    for (u32 n = 0; n < nbSymbols; n++) {
-        u32 const w = S->weights[n];
-        if (!w) continue;
-        u32 const len = (1u << w) >> 1, s0 = S->symStart[n];
-        u16 const cell = (u16)(((tableLog + 1 - w) << 8) | n);
-        for (u32 u = (u32)lane; u < len; u += ZSA_WAVE) S->huf[s0 + u] = cell;
-    }
-    wv_sync();
-    return S->u[ZU_tmp];
+    (void)nbSymbols;
+    return iSize + 1;
 }
 
 // huf_decompress.c:514-564: one stream, run by one lane.  Returns 0 ok / 1 corrupted.
