@@ -644,79 +644,80 @@ ZSA_DEV u32 zsa_huf_buildCTable_wave(ZsaEncShared* S, ZsaHufCT* ct, const u32* c
     wv_sync();
     return maxNbBits;
 }
-// huf_compress.c:147-187 HUF_compressWeights; returns size; 0 "not compressible", 1 "rle", 0xFFFFFFFF error
-ZSA_DEV u32 zsa_huf_compressWeights(ZsaEncShared* S, u8* dst, const u8* weights, u32 wtSize)
+// HUF_compressWeights (huf_compress.c:147-187) by the whole wave: histogram of the weights by ballots (13 values), shares and
+// encode table by the wave routines the sequence section uses; the description's bits and the stream itself -- two interleaved
+// states, one chain -- on lane 0.  weights: LDS.  Returns size; 0 "not compressible", 1 "rle", 0xFFFFFFFF error.  Uniform.
+ZSA_DEV u32 zsa_huf_compressWeights_wave(ZsaEncShared* S, u8* dst, const u8* weights, u32 wtSize, int lane)
 {
-    u8* op = dst;
-    u32 maxSV = ZSA_HUF_TABLELOG_MAX, tableLog = 6;
-    u32 cnt[ZSA_HUF_TABLELOG_MAX + 1];
-    s16 norm[ZSA_HUF_TABLELOG_MAX + 1];
     if (wtSize <= 1) return 0;
-    for (u32 i = 0; i <= ZSA_HUF_TABLELOG_MAX; i++) cnt[i] = 0;
-    for (u32 i = 0; i < wtSize; i++) cnt[weights[i]]++;
-    while (!cnt[maxSV]) maxSV--;
-    {   u32 maxCount = 0;
-        for (u32 s = 0; s <= maxSV; s++) if (cnt[s] > maxCount) maxCount = cnt[s];
-        if (maxCount == wtSize) return 1;
-        if (maxCount == 1) return 0;
+    u32 w[4];
+    for (u32 k = 0; k < 4; k++) { u32 const n = (u32)lane + 64u * k; w[k] = n < wtSize ? weights[n] : 0xFFu; }
+    u32 myCount = 0;   // lane t: how many symbols have weight t
+    for (u32 t = 0; t <= ZSA_HUF_TABLELOG_MAX; t++) {
+        u32 c = 0;
+        for (u32 k = 0; k < 4; k++) c += (u32)__builtin_popcountll(wv_ballot(w[k] == t));
+        if ((u32)lane == t) myCount = c;
     }
-    tableLog = zsa_fse_optimalTableLog(tableLog, wtSize, maxSV, 2);
-    if (zsa_fse_normalizeCount(norm, tableLog, cnt, wtSize, maxSV, 0)) return 0xFFFFFFFFu;
-    {   u32 const h = zsa_fse_writeNCount(op, norm, maxSV, tableLog);
-        if (h == 0) return 0xFFFFFFFFu;
-        op += h;
-    }
-    zsa_fse_buildCTable(S, S->wtNext, S->wtDfs, S->wtDnb, norm, maxSV, tableLog);
-    {   // fse_compress.c:551-608 FSE_compress_usingCTable_generic
+    u32 const maxSV = 63u - (u32)__builtin_clzll(wv_ballot(myCount != 0));
+    u32 const maxCount = wv_reduce_max(myCount);
+    if (maxCount == wtSize) return 1;
+    if (maxCount == 1) return 0;
+    u32 const tableLog = zsa_fse_optimalTableLog(6, wtSize, maxSV, 2);
+    u32* const wcount = (u32*)&S->norm[64];   // (16 words behind the shares)
+    if (lane < 16) wcount[lane] = myCount;
+    wv_lds_fence();
+    if (zsa_fse_normalizeCount_wave(S->norm, tableLog, wcount, wtSize, maxSV, 0, lane)) return 0xFFFFFFFFu;
+    wv_lds_fence();
+    u32 h = 0;
+    if (lane == 0) h = zsa_fse_writeNCount(dst, S->norm, maxSV, tableLog);
+    h = wv_readlane(h, 0);
+    if (h == 0) return 0xFFFFFFFFu;
+    zsa_fse_buildCTable_wave(S, S->wtNext, S->wtDfs, S->wtDnb, S->norm, maxSV, tableLog, lane);
+    wv_sync();
+    if (wtSize <= 2) return 0;
+    u32 n = 0;
+    if (lane == 0) {   // fse_compress.c:551-608 FSE_compress_usingCTable_generic
+        u8* const op = dst + h;
         const u8* ip = weights + wtSize;
         u32 srcSize = wtSize;
-        ZsaBitW w;
+        ZsaBitW bw;
         ZsaFseCState s1, s2;
-        if (srcSize <= 2) return 0;
-        zsa_bw_init(w, op);
+        zsa_bw_init(bw, op);
         if (srcSize & 1) {
             zsa_fse_initCState2(s1, S->wtNext, S->wtDfs, S->wtDnb, tableLog, *--ip);
             zsa_fse_initCState2(s2, S->wtNext, S->wtDfs, S->wtDnb, tableLog, *--ip);
-            zsa_fse_encodeSymbol(w, s1, *--ip);
+            zsa_fse_encodeSymbol(bw, s1, *--ip);
         } else {
             zsa_fse_initCState2(s2, S->wtNext, S->wtDfs, S->wtDnb, tableLog, *--ip);
             zsa_fse_initCState2(s1, S->wtNext, S->wtDfs, S->wtDnb, tableLog, *--ip);
         }
         srcSize -= 2;
-        if (srcSize & 2) { zsa_fse_encodeSymbol(w, s2, *--ip); zsa_fse_encodeSymbol(w, s1, *--ip); }
+        if (srcSize & 2) { zsa_fse_encodeSymbol(bw, s2, *--ip); zsa_fse_encodeSymbol(bw, s1, *--ip); }
         while (ip > weights) {
-            zsa_fse_encodeSymbol(w, s2, *--ip); zsa_fse_encodeSymbol(w, s1, *--ip);
-            zsa_fse_encodeSymbol(w, s2, *--ip); zsa_fse_encodeSymbol(w, s1, *--ip);
+            zsa_fse_encodeSymbol(bw, s2, *--ip); zsa_fse_encodeSymbol(bw, s1, *--ip);
+            zsa_fse_encodeSymbol(bw, s2, *--ip); zsa_fse_encodeSymbol(bw, s1, *--ip);
         }
-        zsa_bw_add(w, s2.value, s2.stateLog);
-        zsa_bw_add(w, s1.value, s1.stateLog);
-        op += zsa_bw_close(w);
+        zsa_bw_add(bw, s2.value, s2.stateLog);
+        zsa_bw_add(bw, s1.value, s1.stateLog);
+        n = h + zsa_bw_close(bw);
     }
-    return (u32)(op - dst);
+    return wv_readlane(n, 0);
 }
-// huf_compress.c:230-268 HUF_writeCTable_wksp; returns header size, 0 on error (uniform).  The weights are derived by all
-// lanes; their FSE compression (a few dozen symbols of an alphabet of 13) is one short chain on lane 0.
+// huf_compress.c:230-268 HUF_writeCTable_wksp; returns header size, 0 on error (uniform).  All lanes.
 ZSA_DEV u32 zsa_huf_writeCTable(ZsaEncShared* S, u8* dst, const ZsaHufCT* ct, u32 maxSV, u32 huffLog, int lane)
 {
     u8* const huffWeight = S->huffWeight;
     for (u32 n = (u32)lane; n < maxSV; n += ZSA_WAVE) { u32 const b = ct->nbBits[n]; huffWeight[n] = (u8)(b ? huffLog + 1 - b : 0); }
+    if (lane == 0) huffWeight[maxSV] = 0;
     wv_sync();
-    if (lane == 0) {
-        u32 r;
-        u32 const hSize = zsa_huf_compressWeights(S, dst + 1, huffWeight, maxSV);
-        if (hSize == 0xFFFFFFFFu) r = 0;
-        else if ((hSize > 1) & (hSize < maxSV / 2)) { dst[0] = (u8)hSize; r = hSize + 1; }
-        else if (maxSV > (256 - 128)) r = 0;
-        else {
-            dst[0] = (u8)(128 + (maxSV - 1));
-            huffWeight[maxSV] = 0;
-            for (u32 n = 0; n < maxSV; n += 2) dst[(n / 2) + 1] = (u8)((huffWeight[n] << 4) + huffWeight[n + 1]);
-            r = ((maxSV + 1) / 2) + 1;
-        }
-        S->u[EU_s0] = r;
-    }
+    u32 const hSize = zsa_huf_compressWeights_wave(S, dst + 1, huffWeight, maxSV, lane);
     wv_sync();
-    return S->u[EU_s0];
+    if (hSize == 0xFFFFFFFFu) return 0;
+    if ((hSize > 1) & (hSize < maxSV / 2)) { if (lane == 0) dst[0] = (u8)hSize; return hSize + 1; }
+    if (maxSV > (256 - 128)) return 0;
+    if (lane == 0) dst[0] = (u8)(128 + (maxSV - 1));
+    for (u32 n = 2u * (u32)lane; n < maxSV; n += 2u * ZSA_WAVE) dst[(n / 2) + 1] = (u8)((huffWeight[n] << 4) + huffWeight[n + 1]);
+    return ((maxSV + 1) / 2) + 1;
 }
 ZSA_DEV u32 zsa_huf_estimate(const ZsaHufCT* ct, const u32* count, u32 maxSV, int lane)
 {   // huf_compress.c:768-777 (a wave sum; a block's literals are at most 128 KiB, so the bit count fits 32 bits)
