@@ -58,6 +58,39 @@ def test_emulated_kernels_match_oracle(emu, oracle):
             assert m == len(d) and out.raw[:m] == d
 
 
+def test_emulated_huffman_tables_seeded(emu, oracle):
+    """Literal-heavy inputs with shaped symbol statistics: the wave-level Huffman code construction (zsa_encode.h:
+    zsa_huf_buildCTable_wave -- key ranking, quick sort of the large-count buckets, code values by ballots; weight description
+    by the wave FSE routines) and the decoder's table (zsa_decode.h: zsa_huf_buildTable) against the oracle.  Equal counts
+    (the sort's order among them reaches the output), deep trees (length limiting), 4-bit and FSE-coded weight descriptions."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    cases = []
+    for n, nsym, kind in ((300, 3, 0), (1500, 17, 1), (4000, 40, 2), (9000, 90, 3), (20000, 180, 4), (50000, 256, 2),
+                          (131072, 256, 3), (140000, 90, 1), (700, 8, 2), (60000, 256, 0)):
+        if kind == 0: p = rng.dirichlet(np.ones(nsym) * 0.3)
+        elif kind == 1: p = 0.5 ** np.arange(1, nsym + 1); p = p / p.sum()
+        elif kind == 2: p = np.ones(nsym) / nsym
+        elif kind == 3: p = np.repeat(rng.dirichlet(np.ones(nsym // 8 + 1)), 8)[:nsym]; p = p / p.sum()
+        else: p = 1.0 / np.arange(1, nsym + 1); p = p / p.sum()
+        syms = rng.permutation(256)[:nsym]
+        if kind in (2, 3):   # exact ties: a shuffled multiset
+            d = np.repeat(syms, np.maximum(1, (p * n).astype(int))); rng.shuffle(d)
+        else:
+            d = rng.choice(syms, size=n, p=p)
+        cases.append(d.astype(np.uint8).tobytes())
+    for d in cases:
+        for level in (1, 5):
+            want = oracle.compress(d, level)
+            cap = zstd_amd.CompressBound(len(d))
+            buf = ctypes.create_string_buffer(cap + 1)
+            n = emu.emu_compress_level(buf, cap, d, len(d), level)
+            assert buf.raw[:n] == want, (len(d), level)
+            out = ctypes.create_string_buffer(len(d) + 1)
+            m = emu.emu_decompress(out, len(d), want, len(want))
+            assert m == len(d) and out.raw[:m] == d
+
+
 def test_emulated_decoder_errors(emu, oracle):
     d = corpus.frames("json", 5000, 1, 3)[0]
     c = oracle.compress(d, 1)
