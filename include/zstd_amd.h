@@ -58,6 +58,8 @@ size_t zsa_decompress_usingDDict(void* dst, size_t dstCapacity, const void* src,
  *    outSize[i] receives bytes written or (size_t)-error for frame i.  Returns 0, or an error code when the
  *    batch as a whole could not run (no device, allocation failure).
  *    Go side: CompressBatch / (*BulkProcessor).CompressBatch in INTEGRATION.md.
+ *    Batches of 8 MiB and more are staged by helper threads that live for the call (ZSTD_AMD_COPY_THREADS,
+ *    default 4, 1 = none; they copy between the caller's buffers and pinned memory and make no HIP calls).
  * ------------------------------------------------------------------------------------------------------- */
 size_t zsa_compress_batch(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCapacity,
                           size_t* outSize, size_t nFrames, int compressionLevel, const zsa_CDict* cdict /* or NULL */);
