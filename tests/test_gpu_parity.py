@@ -334,6 +334,28 @@ def test_large_host_batch_staged_by_helper_threads(z, oracle):
     assert z.DecompressBatch(out, [131072] * 80) == rand
 
 
+def test_large_host_batches_from_many_threads(z, oracle):
+    # four caller threads, each with its own staging, stream and helper threads, large batches at the same time
+    import threading
+    from zstd_amd import corpus
+    sets = [corpus.frames("log", 131072, 80, 910 + t) + corpus.frames("json", 30000, 60, 920 + t) for t in range(4)]
+    want = [z.CompressBatch(fs, 1) for fs in sets]
+    assert want[0][5] == oracle.compress(sets[0][5], 1)
+    errors = []
+    def work(t):
+        try:
+            for _ in range(2):
+                got = z.CompressBatch(sets[t], 1)
+                assert got == want[t]
+                assert z.DecompressBatch(got, [len(f) for f in sets[t]]) == sets[t]
+        except BaseException as e:   # noqa: BLE001
+            errors.append((t, repr(e)))
+    th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for x in th: x.start()
+    for x in th: x.join()
+    assert not errors, errors
+
+
 def test_dfast_levels_match_golden(z, oracle):
     """levels 3 and 4 (and 2 at <= 256 KB, 0 = default) -- strategy ZSTD_dfast -- byte-identical to the
     reference-generated fixture, multi-block frames included (1 MiB at level 3 is BASELINE config 5's chunk)"""
