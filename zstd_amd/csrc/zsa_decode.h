@@ -8,12 +8,13 @@
 //   sequences         zstd_decompress_block.c:1185-1299, 1569-1654  execution :873-1060
 //
 // Mapping onto the wave:
-//   * decode tables live in LDS (Huffman 2^tableLog x u16, three sequence tables x u64 cells);
+//   * decode tables live in LDS (Huffman 2^tableLog x u16, three sequence tables x u64 cells) and are built by the
+//     whole wave (zsa_huf_buildTable; zsa_buildSeqTable over zsa_common.h's zsa_fse_spread_wave);
 //   * the four Huffman streams of a literal section run on four lanes;
 //   * the sequence bitstream is one serial chain (lane 0), decoded 64 sequences at a time into LDS;
 //   * the 64 lanes then execute that batch: a wave prefix-sum gives every sequence its output position,
-//     literals are copied by all lanes at once, matches are copied in sequence order 64 bytes per step,
-//     with a memory fence only when a match reads bytes the wave has not yet made visible.
+//     literals are copied by all lanes at once, independent matches likewise, dependent matches in rounds (a match is
+//     ready when no unfinished match lies in the range its source comes from), with a fence between rounds.
 // Serial sections run under `lane == 0` and publish through LDS; every wv_* call is reached by all lanes.
 #pragma once
 #include "zsa_common.h"

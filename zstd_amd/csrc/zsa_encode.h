@@ -1,23 +1,27 @@
-// zsa_encode.h -- device-side Zstandard level-1 (ZSTD_fast) frame compressor: one 64-lane wave per frame.
+// zsa_encode.h -- device-side Zstandard frame compressor (ZSTD_fast .. ZSTD_lazy2): one 64-lane wave per frame.
 //
 // Replaces, for independent frames compressed in one launch, what the reference reaches through
 // ZSTD_compress / ZSTD_compress_usingCDict (zstd.go:108,115; zstd_bulk.go:77,86).  Output is byte-identical
-// to libzstd 1.5.5 for the same cParams (resolved on the host, zsa_host.cpp):
+// to libzstd 1.5.5 for the same cParams (zsa_params.h resolves them, on the host and in the kernels):
 //   frame / block loop   zstd_compress.c:4392-4520, 4222-4283, 5107-5144
-//   parse                zstd_fast.c:143-403 (noDict), :459-656 (attached dictionary)
+//   parse                zstd_fast.c:143-403 (noDict), :459-656 (attached dictionary), :658-960 (dictionary as an external
+//                        segment); zstd_double_fast.c:98-305; zstd_lazy.c:621-1757
 //   literals             zstd_compress_literals.c:40-236, huf_compress.c:147-1406, hist.c:30-165
 //   sequences            zstd_compress.c:2637-2986, zstd_compress_sequences.c:157-383, fse_compress.c:69-525
 //
 // Mapping onto the wave:
-//   * one 64-lane wave per frame; the frame's match table lives in the workgroup's slice of the global scratch
-//     (L2 resident), LDS holds a source ring, a 4-bit filter of the table and a bitmap for shared-cell detection;
-//   * ZSTD_fast without a dictionary parses 64 positions per step (zsa_parse.h: chunk path + general window
-//     evaluation), ZSTD_fast with an attached dictionary likewise (zsa_parse_dict.h), greedy/lazy/lazy2 evaluate the
-//     candidates of one position across lanes (zsa_lazy.h); ZSTD_dfast and the ext-dict corner of ZSTD_fast
-//     still run the reference's loop on lane 0;
+//   * one 64-lane wave per frame; the frame's match table lives in the workgroup's slice of the global scratch,
+//     LDS holds a source ring, a filter of the table (4 or 2 bits per cell) and a bitmap for shared-cell detection;
+//   * every parser evaluates windows of consecutive positions across the lanes and takes the reference's event with one
+//     ballot: ZSTD_fast without a dictionary (zsa_parse.h: chunk path + general evaluation), with a dictionary
+//     (zsa_parse_dict.h: attached, external segment), ZSTD_dfast (zsa_dfast.h); greedy/lazy/lazy2 evaluate the candidates
+//     of one position across lanes (zsa_lazy.h).  No parser runs under `lane == 0`;
 //   * literals are gathered by all 64 lanes from the recorded triples (wave prefix sums), histograms use LDS
-//     atomics from all lanes, the four Huffman streams are packed by four lanes, the FSE sequence bitstream by all;
-//   * table construction (Huffman tree, FSE normalisation) is short and serial on lane 0.
+//     atomics from all lanes, Huffman streams and the FSE sequence bitstream are packed by all lanes;
+//   * tables are built by the whole wave: FSE shares and state tables (zsa_common.h: zsa_fse_spread_wave), the Huffman
+//     code (ranking into the reference's sort order, code values by ballots).  What stays on lane 0 are dependency
+//     chains: the tree's two-queue merge, the quick sort of large-count buckets (its order among equal counts reaches the
+//     output), the FSE stream of the Huffman weights, bit-serial table descriptions, headers.
 // Serial sections run under `lane == 0` and publish through LDS; every wv_* call is reached by all lanes.
 #pragma once
 #include "zsa_common.h"
