@@ -309,6 +309,7 @@ ZSA_DEV void zsa_parse_general_body(const TAB T, u32* ringWords, u8* tags, const
                 }
                 ip0 += rLength;
                 if (lane == 0) seqOut[nbSeq] = zsa_packseq(0, rLength - ZSA_MINMATCH, 1);
+                ZSA_STAT(5);
                 nbSeq++;
                 anchor = ip0;
                 if (R.hi < ip0 - 2 + 512 && R.hi < R.limit) zsa_ring_fill(R, ip0 - 2 + 1024, lane);
@@ -397,6 +398,7 @@ ZSA_DEV void zsa_parse_general_body(const TAB T, u32* ringWords, u8* tags, const
                 }
                 ip0 += rLength;
                 if (lane == 0) seqOut[nbSeq] = zsa_packseq(0, rLength - ZSA_MINMATCH, 1);
+                ZSA_STAT(5);
                 nbSeq++;
                 anchor = ip0;
                 chkRep2 = (ip0 <= ilimit) && rep2 > 0;
@@ -488,6 +490,7 @@ ZSA_DEV void zsa_parse_general_body(const TAB T, u32* ringWords, u8* tags, const
                 mLength = 4 + bwd + fwd;
             }
             if (lane == 0) seqOut[nbSeq] = zsa_packseq(ip0 - anchor, mLength - ZSA_MINMATCH, offcode);
+            ZSA_STAT(5);
             nbSeq++;
             ip0 += mLength;
             anchor = ip0;
@@ -567,8 +570,11 @@ ZSA_DEVFN u32 zsa_ring_fill_far(u8* ringB, const u8* src, u32 hi, u32 want, u32 
     zsa_ring_fill(R, want, wv_lane());
     return R.hi;
 }
-// (written with integer flags and one flat loop on purpose: the loop-carried state then stays in scalar registers and every
-// branch is a scalar compare; booleans carried around a loop turn into 64-bit lane masks)
+// The event loop is written so that its loop-carried state stays in scalar registers and every decision is a scalar
+// compare and branch: one kind variable instead of flags, masks and offsets updated the same way for every kind of event.
+//   M1 / M2: lanes of the chunk whose 4 bytes equal the 4 bytes rep1 / rep2 behind them (0 for an offset of 0).  They are
+// made when the chunk is set up; an event then makes the mask of the offset it used -- the read rides on the memory round
+// trip of its match extension -- which becomes M1 whatever the kind of event (a repcode event reproduces the mask it used).
 template <int MLS>
 ZSA_DEVFN void zsa_parse_chunk(const ZsaTabFilt Tin, u32* ringWords, const ZsaParseCtx* Cp, ZsaParseState* stp, u32* backoff)
 {
@@ -587,66 +593,36 @@ ZSA_DEVFN void zsa_parse_chunk(const ZsaTabFilt Tin, u32* ringWords, const ZsaPa
     u32 ip0 = wv_uniform(st.ip0), anchor = wv_uniform(st.anchor), rep1 = wv_uniform(st.rep1), rep2 = wv_uniform(st.rep2), nbSeq = wv_uniform(st.nbSeq);
     u32 chk = wv_uniform(st.chkRep2), mid = wv_uniform(st.midEpisode);
     u32 nextStep = mid ? wv_uniform(st.nextStep) : ip0 + 128;
-    u32 winB = 0, winValid = 0, winEnd = 0;                 // chunk base; lanes [0, winValid) have exact probes (0: no chunk); winEnd = winB + min(63, winValid)
-    u32 ipStop = 0;                                         // beyond it no pair can be decided here: min(winB + min(61, winValid - 2), nextStep - 7)
-    u64 winH = 0;                                           // lanes whose probe passes the filter
-    u64 wv64 = 0; u32 whash = 0, wcell = 0, wnib = 0;       // per lane: source word, cell number, own cell value, filter nibble at set-up
-    u32 wcand = 0;                                          // per lane with a table hit: the candidate's position
-    u32 insV = 0;                                           // per lane: the position entered the table since set-up (not yet written)
-    u32 lateA = 0, lateB = 0;                               // positions beyond the chunk that enter the table after what is pending
     u32* const tabP = T.p;
-    u64 M1 = 0, M2 = 0; u32 M1off = 0, M2off = 0;
-#define ZSA_REPMASK(off, OUT) do { \
+    // the lanes of a chunk whose 4 bytes equal the 4 bytes `off` behind them; lanes below `from` are never asked (their
+    // positions lie behind the parse) and may hold anything
+#define ZSA_REPMASK(off, from, OUT) do { \
         u32 const a_ = winB + (u32)lane - 2 - (off); \
         u32 rv_ = zsa_ring32(R, a_);                                 /* masked ring address, always legal */ \
-        if (ip0 - 2 - (off) < R.lo) {                                /* uniform: older than the ring (in the block: chunks start at or below safeEnd) */ \
-            rv_ = ~(u32)wv64; \
-            if ((u32)lane >= o) rv_ = wv_ldg32_now(R.src + a_); \
+        if (winB + (from) - 2 - (off) < R.lo) {                      /* uniform: older than the ring (in the block: chunks start at or below safeEnd) */ \
+            bool const need_ = (u32)lane >= (from);                  /* (no per-lane branch: the other lanes read the first needed address) */ \
+            rv_ = wv_ldg32_now(R.src + (need_ ? a_ : winB + (from) - 2 - (off))); \
+            if (!need_) rv_ = ~(u32)wv64; \
         } \
         OUT = wv_ballot(rv_ == (u32)wv64); } while (0)
-    for (;;) {
-        if (ip0 > ipStop) {   // the step is about to grow (:322-327), or no pair of the chunk at hand can be decided
-            // write the positions that entered the table since the chunk was set up.  Lanes below winValid fall into
-            // distinct cells that nothing else has written since; the few beyond it follow one by one, in position order
-            // (== time order), then the (at most two) positions beyond the chunk
-            if (winValid) {
-                bool const mine = insV != 0;
-                if (mine && (u32)lane < winValid) { wv_stg_cell(tabP + whash, wcell); u32 const d = wnib ^ T.top(wcell); if (d) T.fxor(whash, d); }
-                for (u64 t = wv_ballot(mine && (u32)lane >= winValid); t; t &= t - 1) {
-                    wv_lds_fence();
-                    ZSA_STAT(7);
-                    if (lane == __builtin_ctzll(t)) { wv_stg_cell(tabP + whash, wcell); u32 const d = T.fget(whash) ^ T.top(wcell); if (d) T.fxor(whash, d); }
-                }
-                wv_lds_fence();
-                insV = 0;
-            }
-            winValid = 0; ipStop = 0;
-            if (lateB) {
-                if (R.hi < lateB + 16 && R.hi < R.limit) { R.hi = wv_uniform(zsa_ring_fill_far(R.b, R.src, R.hi, lateB + 1024, R.limit)); if (R.hi - R.lo > ZSA_RING_BYTES) R.lo = R.hi - ZSA_RING_BYTES; }
-                u32 const pp = lane == 0 ? lateA : lateB;
-                u32 hh = 0, cell = 0;
-                if (lane < 2) { u64 const wd = zsa_ring64(R, pp - 2); hh = zsa_hashT<MLS>(wd, hlog); cell = ZSA_CELL(pp, wd); }
-                if (lane == 0 && lateA) { wv_stg_cell(tabP + hh, cell); u32 const d = T.fget(hh) ^ T.top(cell); if (d) T.fxor(hh, d); }
-                wv_lds_fence();
-                if (lane == 1) { wv_stg_cell(tabP + hh, cell); u32 const d = T.fget(hh) ^ T.top(cell); if (d) T.fxor(hh, d); }
-                wv_lds_fence();
-                lateA = lateB = 0;
-            }
-            if (nextStep - ip0 <= 6 || ip0 > safeEnd) break;
-            {   u32 const want = ip0 - 2 + 1024;
-                if (R.hi < want && R.hi < R.limit) { R.hi = wv_uniform(zsa_ring_fill_far(R.b, R.src, R.hi, want, R.limit)); if (R.hi - R.lo > ZSA_RING_BYTES) R.lo = R.hi - ZSA_RING_BYTES; }
-            }
-            ZSA_STAT(0);
-            winB = ip0;
-            u32 const q = winB + (u32)lane;
-            wv64 = zsa_ring64(R, q - 2);
-            whash = zsa_hashT<MLS>(wv64, hlog);
-            wcell = (ZSA_FPV(wv64) << posBits) | q;
-            wnib = T.fget(whash);
-            winH = wv_ballot(wnib == T.top(wcell));
-            // lanes that share their cell with another lane: the first lane to reach a cell's bit finds it clear, the
-            // others find it set and clear it again, which tells the first one
-            u32* const dw = T.dupWord(whash);
+    for (;;) {   // one chunk per iteration
+        if (nextStep - ip0 <= 6 || ip0 > safeEnd) break;        // the step is about to grow (:322-327), or the block ends
+        {   u32 const want = ip0 - 2 + 1024;
+            if (R.hi < want && R.hi < R.limit) { R.hi = wv_uniform(zsa_ring_fill_far(R.b, R.src, R.hi, want, R.limit)); if (R.hi - R.lo > ZSA_RING_BYTES) R.lo = R.hi - ZSA_RING_BYTES; }
+        }
+        ZSA_STAT(0);
+        // ---- set-up: lane k <-> position winB + k
+        u32 const winB = ip0;
+        u32 const q = winB + (u32)lane;
+        u64 const wv64 = zsa_ring64(R, q - 2);                  // source word
+        u32 const whash = zsa_hashT<MLS>(wv64, hlog);           // cell number
+        u32 const wcell = (ZSA_FPV(wv64) << posBits) | q;       // the lane's own cell value
+        u32 const wnib = T.fget(whash);                         // filter bits of the cell at set-up
+        u64 H = wv_ballot(wnib == T.top(wcell));                // lanes whose probe passes the filter
+        // lanes that share their cell with another lane: the first lane to reach a cell's bit finds it clear, the
+        // others find it set and clear it again, which tells the first one
+        u32 winValid;
+        {   u32* const dw = T.dupWord(whash);
             u32 const bit = 1u << (whash & 31u);
             bool const late = (wv_atomic_or_lds(dw, bit) & bit) != 0;
             wv_lds_fence();
@@ -658,123 +634,147 @@ ZSA_DEVFN void zsa_parse_chunk(const ZsaTabFilt Tin, u32* ringWords, const ZsaPa
             wv_lds_fence();
             u64 const G = wv_ballot(shares);
             u64 const G2 = G & (G - 1);
-            winValid = G2 ? (u32)__builtin_ctzll(G2) : 64u;
-            M1off = M2off = 0;
-            if (winValid < 2) { *backoff = ip0 + 96; winValid = 0; ZSA_STAT(4); break; }   // (lanes 0 and 1 share a cell: runs of equal bytes)
-            winEnd = winB + (winValid < 63 ? winValid : 63u);
-            {   u32 const a = winEnd - 2, b = nextStep - 7;   // (winB + min(61, winValid - 2))
-                ipStop = a < b ? a : b;
+            winValid = G2 ? (u32)__builtin_ctzll(G2) : 64u;     // lanes [0, winValid) have exact probes
+        }
+        if (winValid < 2) { *backoff = ip0 + 96; ZSA_STAT(4); break; }   // (lanes 0 and 1 share a cell: runs of equal bytes)
+        u32 const winEnd = winB + (winValid < 63 ? winValid : 63u);
+        // The table does not change while the chunk is scanned (commits are deferred), so the cells are fetched here, once per
+        // chunk and for all lanes that pass the filter at the same time, instead of once per event in the event's own
+        // dependency chain: a cell gives the candidate's position and the fingerprint bits the filter does not hold, and
+        // H keeps the lanes whose whole fingerprint agrees.  (Measured: fetching the candidates' bytes here as well --
+        // 8 on either side, so that short matches need no memory at all -- adds nothing on top of this.)
+        u32 wcand;                                              // per lane with a table hit: the candidate's position
+        {   bool const probe = ((H >> lane) & 1) != 0 && (u32)lane < winValid;
+            u32 cx = 1u << posBits;
+            if (probe) cx = wv_ldg_cell(tabP + whash) ^ wcell;
+            wcand = (cx & posMask) ^ q;                                      // (the low bits of wcell are q)
+            H = wv_ballot((cx >> posBits) == 0 && wcand >= prefixStartIndex);
+        }
+        u64 M1 = 0, M2 = 0;
+        if (rep1) ZSA_REPMASK(rep1, 0u, M1);
+        if (rep2) ZSA_REPMASK(rep2, 0u, M2);
+        u64 M2c = chk ? M2 : 0;                                 // M2 where the immediate-repcode check is due: after an event (not at a search that continues)
+        u32 limEnd = winEnd < nextStep - 3 ? winEnd : nextStep - 3;   // pairs are decided here while both lanes lie below winEnd and the step stays 2
+        u32 insV = 0;                                           // per lane: the position entered the table since set-up (not yet written)
+        u32 lateA = 0, lateB = 0;                               // positions beyond the chunk that enter the table after what is pending
+        // ---- the events of the chunk, in the reference's order: the immediate repcode at ip0 (zstd_fast.c:311-324), then per
+        // pair the repcode check at ip0 + 2i + 2 and the two table checks
+        for (;;) {
+            u32 const o = ip0 - winB;
+            u32 kind, cur, m, four, eBack, cnt;                 // kind 0: immediate repcode, 1: repcode at a pair's ip2, 2: table
+            if (((M2c >> o) & 1ull) != 0) { kind = 0; cur = ip0; m = ip0 - rep2; four = 4; eBack = 0; cnt = 1; }
+            else {
+                u32 const lim = (limEnd - ip0) & ~1u;           // twice the number of pairs decided here, >= 2
+                u64 const Hs = H >> o;
+                u32 fh = Hs ? (u32)__builtin_ctzll(Hs) : 64u;
+                if (fh >= lim) fh = 64;
+                u64 const Rs = (M1 >> o) & 0x5555555555555554ull;
+                u32 fr = Rs ? (u32)__builtin_ctzll(Rs) : 64u;
+                if (fr > lim) fr = 64;
+                if (fr != 64 && fr <= fh + 2) { kind = 1; cur = ip0 + fr; m = cur - rep1; four = 4; eBack = 1; cnt = fr; }
+                else if (fh != 64) {
+                    kind = 2; cur = ip0 + fh; four = 0; cnt = fh + 2;
+                    m = wv_readlane(wcand, (int)(o + fh));      // the candidate position was fetched when the chunk was set up
+                    u32 const ba = cur - anchor, bb = m - prefixStartIndex;
+                    eBack = ba < bb ? ba : bb;
+                } else {   // no event: all pairs enter the table, the search goes on behind the chunk
+                    ZSA_STAT(2);
+                    insV |= (u32)((u32)lane - o < lim);
+                    ip0 += lim;
+                    mid = 1; chk = 0;
+                    break;
+                }
             }
-            // The table does not change while the chunk is scanned (commits are deferred), so the cells are fetched here, once per
-            // chunk and for all lanes that pass the filter at the same time, instead of once per event in the event's own
-            // dependency chain: a cell gives the candidate's position and the fingerprint bits the filter does not hold, and
-            // winH keeps the lanes whose whole fingerprint agrees.  (Measured: fetching the candidates' bytes here as well --
-            // 8 on either side, so that short matches need no memory at all -- adds nothing on top of this.)
-            {   bool const probe = ((winH >> lane) & 1) != 0 && (u32)lane < winValid;
-                u32 cx = 1u << posBits;
-                if (probe) cx = wv_ldg_cell(tabP + whash) ^ wcell;
-                wcand = (cx & posMask) ^ q;                                      // (the low bits of wcell are q)
-                winH = wv_ballot((cx >> posBits) == 0 && wcand >= prefixStartIndex);
+            // one round of match extension: lanes 0..15 compare 8 bytes each forwards from (cur + four, m + four), lanes
+            // 48..63 one byte each backwards from (cur - 1, m - 1) for at most eBack bytes (the source side lies in the ring;
+            // a candidate older than the ring costs one or two lines).  A repcode's 4 bytes are known to match (:259-265).
+            // The same round trip brings the mask of the event's offset.
+            u32 const L = cur - winB, off = cur - m;
+            u32 fwd, bwd;
+            u64 Mn;
+            {   bool const fw = lane < 16;
+                u32 const k = (u32)lane - 48u;
+                u32 const dl = fw ? four + 8u * (u32)lane : 0u - 1u - k;
+                u32 const a = cur + dl - 2, b = m + dl - 2;                  // frame offsets
+                u64 const sa = zsa_ring64(R, a);                             // masked ring address: legal in every lane
+                u32 rv = zsa_ring32(R, q - 2 - off);
+                u64 sb;
+                if (m - 2 >= R.lo + 16) sb = zsa_ring64(R, b);               // uniform: the candidate lies in the ring as well
+                else {   // (no per-lane branches in this loop: lanes that take no part read the candidate's first bytes)
+                    bool const need = fw | ((lane >= 48) & (k < eBack));
+                    sb = wv_ldg64_now(R.src + (need ? b : m + four - 2));
+                    if (!need) sb = ~sa;
+                    if (m - 2 < R.lo) {
+                        bool const needR = (u32)lane >= L;
+                        rv = wv_ldg32_now(R.src + (needR ? q : cur) - 2 - off);
+                        if (!needR) rv = ~(u32)wv64;
+                    }
+                }
+                u64 const diff = sa ^ sb;
+                u32 const eq = diff ? ((u32)__builtin_ctzll(diff) >> 3) : 8;
+                bool const stop = (fw & (eq < 8)) | ((!fw) & ((k >= eBack) | (eq == 0)));     // (bitwise: no per-lane branch)
+                u64 const sbal = wv_ballot(stop);
+                Mn = wv_ballot(rv == (u32)wv64);
+                u32 const sf = (u32)sbal & 0xFFFFu, sk = (u32)(sbal >> 48);
+                if (sf) { int const f = __builtin_ctz(sf); fwd = 8u * (u32)f + wv_readlane(eq, f); }
+                else fwd = 128 + wv_uniform(zsa_count_far(R.b, R.src, R.lo, R.hi, R.limit, cur + four - 2 + 128, m + four - 2 + 128, iend - 2));   // (a call's result counts as per-lane)
+                if (sk) bwd = (u32)__builtin_ctz(sk);
+                else bwd = wv_uniform(zsa_back_far(R.b, R.src, R.lo, R.hi, R.limit, cur - 2, m - 2, eBack));
+            }
+            if (kind == 2 && fwd < 4) { ZSA_STAT(6); H &= ~(1ull << L); continue; }   // the fingerprint let it through, the bytes differ: not an event
+            ZSA_STAT(kind == 0 ? 1 : 3);
+            u32 const start = cur - bwd, mLength = four + bwd + fwd;
+            {   // (packed by the lanes: the vector unit has the spare issue slots here)
+                u32 const vz = (u32)lane & 0u;
+                u64 const sq = zsa_packseq((start - anchor) | vz, (mLength - ZSA_MINMATCH) | vz, (kind == 2 ? off + 3u : 1u) | vz);   // (an immediate repcode starts at the anchor)
+                wv_stg64(seqOut + nbSeq, sq);                              // (every lane, same address, same value: no per-lane branch in this loop)
+            }
+            nbSeq++;
+            ip0 = start + mLength;
+            // positions that enter the table (:266, :278, :300-303): up to the event's pair, plus the next pair's first position
+            // when the second table check hit (step <= 4); an immediate repcode enters its own position (:318).  Then
+            // (:307-309) current0 + 2 and ip0 - 2, in this order.
+            {   u32 lA = 64u, lB = 64u;
+                if (ip0 <= ilimit && kind != 0) {
+                    u32 const pA = cur + (kind == 2 ? 2u : 0u), pB = ip0 - 2;
+                    lA = pA - winB; lB = pB - winB;
+                    if (lB >= 64) { lateB = pB; if (lA >= 64) lateA = pA; }
+                }
+                insV |= (u32)(((u32)lane - o < cnt) | ((u32)lane == lA) | ((u32)lane == lB));
+            }
+            // offsets and their masks: the event's offset comes first; a repcode at ip2 keeps the second one
+            if (kind != 1) { rep2 = rep1; M2 = M1; }
+            rep1 = off; M1 = Mn; M2c = M2;
+            anchor = ip0;
+            limEnd = winEnd; nextStep = ip0 + 128;              // (the step stays 2 for 128 bytes from here)
+            if (ip0 + 2 > winEnd) {                             // no pair of the chunk is left to decide
+                mid = 0;
+                chk = (ip0 <= ilimit && rep2 != 0) ? 1u : 0u;
+                break;
             }
         }
-        u32 const o = ip0 - winB;
-        u32 lim;   // twice the number of pairs decided here, >= 2: both lanes of a pair below winValid, the repcode lane ip0 + 2i + 2 <= 63,
-        {          // no step increase before them
-            u32 const a = nextStep - 3;
-            lim = ((winEnd < a ? winEnd : a) - ip0) & ~1u;
+        // ---- write the positions that entered the table since the chunk was set up.  Lanes below winValid fall into
+        // distinct cells that nothing else has written since; the few beyond it follow one by one, in position order
+        // (== time order), then the (at most two) positions beyond the chunk
+        {   bool const mine = insV != 0;
+            if (mine && (u32)lane < winValid) { wv_stg_cell(tabP + whash, wcell); u32 const d = wnib ^ T.top(wcell); if (d) T.fxor(whash, d); }
+            for (u64 t = wv_ballot(mine && (u32)lane >= winValid); t; t &= t - 1) {
+                wv_lds_fence();
+                ZSA_STAT(7);
+                if (lane == __builtin_ctzll(t)) { wv_stg_cell(tabP + whash, wcell); u32 const d = T.fget(whash) ^ T.top(wcell); if (d) T.fxor(whash, d); }
+            }
+            wv_lds_fence();
         }
-        // repcode compares of the chunk's lanes against the two offsets (4 bytes each, lanes >= o matter): kept while the
-        // offset they were made for lives (M1off / M2off; 0: none)
-        if (chk && M2off != rep2) { ZSA_REPMASK(rep2, M2); M2off = rep2; }
-        if (rep1 && M1off != rep1) { ZSA_REPMASK(rep1, M1); M1off = rep1; }
-        // candidates in the reference's order: the immediate repcode at ip0 (zstd_fast.c:311-324), then per pair the
-        // repcode check at ip0 + 2i + 2 and the two table checks.  One of three kinds of event is taken; what follows is
-        // written with selects rather than branches (see the note above the function).
-        u32 const isR2 = chk & (u32)(M2 >> o) & 1u;
-        chk = 0;
-        u32 fh, fr = 64;
-        {   u64 const Hs = winH >> o;
-            fh = Hs ? (u32)__builtin_ctzll(Hs) : 64u;
-            if (fh >= lim) fh = 64;
-            u64 const Rs = (M1 >> o) & 0x5555555555555554ull;
-            fr = Rs ? (u32)__builtin_ctzll(Rs) : 64u;
-            if (fr > lim || rep1 == 0) fr = 64;
+        if (lateB) {
+            if (R.hi < lateB + 16 && R.hi < R.limit) { R.hi = wv_uniform(zsa_ring_fill_far(R.b, R.src, R.hi, lateB + 1024, R.limit)); if (R.hi - R.lo > ZSA_RING_BYTES) R.lo = R.hi - ZSA_RING_BYTES; }
+            u32 const pp = lane == 0 ? lateA : lateB;
+            u32 hh = 0, cell = 0;
+            if (lane < 2) { u64 const wd = zsa_ring64(R, pp - 2); hh = zsa_hashT<MLS>(wd, hlog); cell = ZSA_CELL(pp, wd); }
+            if (lane == 0 && lateA) { wv_stg_cell(tabP + hh, cell); u32 const d = T.fget(hh) ^ T.top(cell); if (d) T.fxor(hh, d); }
+            wv_lds_fence();
+            if (lane == 1) { wv_stg_cell(tabP + hh, cell); u32 const d = T.fget(hh) ^ T.top(cell); if (d) T.fxor(hh, d); }
+            wv_lds_fence();
         }
-        // (flags by integer arithmetic -- fh, fr are in [0, 64] -- so that they stay 32-bit scalars: written as comparisons the
-        // compiler turns each of them into a 64-bit lane mask and back)
-        u32 const isRep = (isR2 ^ 1u) & ((127u - fr) >> 6) & (((fh + 2u - fr) >> 31) ^ 1u);          // no R2, fr != 64, fr <= fh + 2
-        u32 const isHash = (isR2 ^ 1u) & (isRep ^ 1u) & ((127u - fh) >> 6);                          // neither, fh != 64
-        if ((isR2 | isRep | isHash) == 0) {   // no event: all pairs enter the table, the search goes on
-            ZSA_STAT(2);
-            insV |= ((u32)lane - o < lim) ? 1u : 0u;
-            ip0 += lim;
-            mid = 1;
-            continue;
-        }
-        u32 const cur = ip0 + isRep * fr + isHash * fh;                  // where the event is
-        // a table event: the candidate position was fetched when the chunk was set up
-        u32 const L = (o + fh) & 63u;
-        u32 const m = isHash ? wv_readlane(wcand, (int)L) : cur - (isR2 ? rep2 : rep1);
-        // one round of match extension: lanes 0..15 compare 8 bytes each forwards from (cur + four, m + four), lanes
-        // 48..63 one byte each backwards from (cur - 1, m - 1) for at most eBack bytes (the source side lies in the ring;
-        // a candidate older than the ring costs one or two lines).  A repcode's 4 bytes are known to match (:259-265).
-        u32 const four = isHash ? 0u : 4u;
-        u32 eBack;
-        {   u32 const ba = cur - anchor, bb = m - prefixStartIndex;
-            eBack = isHash ? (ba < bb ? ba : bb) : isRep;
-        }
-        u32 fwd, bwd;
-        {   bool const fw = lane < 16;
-            u32 const k = (u32)lane - 48u;
-            u32 const dl = fw ? four + 8u * (u32)lane : 0u - 1u - k;
-            u32 const a = cur + dl - 2, b = m + dl - 2;                  // frame offsets
-            u64 const sa = zsa_ring64(R, a);                             // masked ring address: legal in every lane
-            u64 sb;
-            if (m - 2 >= R.lo + 16) sb = zsa_ring64(R, b);               // uniform: the candidate lies in the ring as well
-            else { sb = ~sa; if (fw || (lane >= 48 && k < eBack)) sb = wv_ldg64_now(R.src + b); }
-            u64 const diff = sa ^ sb;
-            u32 const eq = diff ? ((u32)__builtin_ctzll(diff) >> 3) : 8;
-            bool const stop = fw ? eq < 8 : !((k < eBack) && eq > 0);
-            u64 const sbal = wv_ballot(stop);
-            u32 const sf = (u32)sbal & 0xFFFFu, sk = (u32)(sbal >> 48);
-            if (sf) { int const f = __builtin_ctz(sf); fwd = 8u * (u32)f + wv_readlane(eq, f); }
-            else fwd = 128 + wv_uniform(zsa_count_far(R.b, R.src, R.lo, R.hi, R.limit, cur + four - 2 + 128, m + four - 2 + 128, iend - 2));   // (a call's result counts as per-lane)
-            if (sk) bwd = (u32)__builtin_ctz(sk);
-            else bwd = wv_uniform(zsa_back_far(R.b, R.src, R.lo, R.hi, R.limit, cur - 2, m - 2, eBack));
-        }
-        if (isHash && fwd < 4) { ZSA_STAT(6); winH &= ~(1ull << L); continue; }   // the fingerprint let it through, the bytes differ: not an event
-        ZSA_STAT(isR2 ? 1 : 3);
-        u32 const start = cur - bwd, mLength = four + bwd + fwd;
-        {   // (packed by the lanes: the vector unit has the spare issue slots here)
-            u32 const vz = (u32)lane & 0u;
-            u64 const sq = zsa_packseq((start - anchor) | vz, (mLength - ZSA_MINMATCH) | vz, (isHash ? (cur - m) + 3u : 1u) | vz);   // (an immediate repcode starts at the anchor)
-            if (lane == 0) wv_stg64(seqOut + nbSeq, sq);
-        }
-        nbSeq++;
-        ip0 = start + mLength;
-        // positions that enter the table (:266, :278, :300-303): up to the event's pair, plus the next pair's first position
-        // when the second table check hit (step <= 4); an immediate repcode enters its own position (:318).  Then
-        // (:307-309) current0 + 2 and ip0 - 2, in this order.
-        {   u32 const cnt = isR2 ? 1u : (isRep ? fr : (fh & ~1u) + 2u + (fh & 1u));
-            u32 const ok = (ip0 <= ilimit && isR2 == 0) ? 1u : 0u;
-            u32 const pA = cur + (isRep ? 0u : 2u), pB = ip0 - 2;
-            u32 const lA = ok ? pA - winB : 64u, lB = ok ? pB - winB : 64u;
-            insV |= (((u32)lane - o < cnt) || (u32)lane == lA || (u32)lane == lB) ? 1u : 0u;
-            if (ok && lB >= 64) { lateB = pB; if (lA >= 64) lateA = pA; }
-        }
-        // offsets (and the masks made for them): a table event pushes a new one, an immediate repcode swaps the two
-        {   u32 const shift = isHash | isR2;
-            u32 const n1 = isHash ? cur - m : (isR2 ? rep2 : rep1), n2 = shift ? rep1 : rep2;
-            u64 const nM1 = isR2 ? M2 : M1, nM2 = shift ? M1 : M2;
-            u32 const nO1 = isR2 ? M2off : M1off, nO2 = shift ? M1off : M2off;
-            rep1 = n1; rep2 = n2; M1 = nM1; M2 = nM2; M1off = nO1; M2off = nO2;
-        }
-        anchor = ip0;
-        nextStep = ip0 + 128; mid = 0;
-        {   u32 const a = winEnd - 2, b = ip0 + 121;
-            ipStop = winValid ? (a < b ? a : b) : 0u;
-        }
-        chk = (ip0 <= ilimit && rep2 != 0) ? 1u : 0u;
     }
 #undef ZSA_REPMASK
     st.ip0 = ip0; st.anchor = anchor; st.rep1 = rep1; st.rep2 = rep2; st.nbSeq = nbSeq; st.chkRep2 = chk;
