@@ -86,6 +86,8 @@ ZSA_DEV unsigned wv_ldg8(const unsigned char* p) { return *p; }
 ZSA_DEV unsigned wv_ldg32(const unsigned char* p) { unsigned v; memcpy(&v, p, 4); return v; }
 ZSA_DEV unsigned long long wv_ldg64(const unsigned char* p) { unsigned long long v; memcpy(&v, p, 8); return v; }
 ZSA_DEV unsigned wv_vzero() { return 0; }
+ZSA_DEV unsigned wv_ff1_64(unsigned long long x) { return x ? (unsigned)__builtin_ctzll(x) : 0xFFFFFFFFu; }
+ZSA_DEV void wv_cold() {}
 ZSA_DEV unsigned wv_ldg_cell(const unsigned* p) { return *p; }
 ZSA_DEV void wv_stg_cell(unsigned* p, unsigned v) { *p = v; }
 ZSA_DEV void wv_stg64(void* p, unsigned long long v) { *(unsigned long long*)p = v; }
@@ -96,6 +98,7 @@ ZSA_DEV unsigned wv_ldg8_now(const unsigned char* p) { return wv_ldg8(p); }
 ZSA_DEV unsigned wv_ldg32_now(const unsigned char* p) { return wv_ldg32(p); }
 ZSA_DEV unsigned long long wv_ldg64_now(const unsigned char* p) { return wv_ldg64(p); }
 template <typename A> ZSA_DEV void wv_join(A&, unsigned&, unsigned&) {}
+template <typename A> ZSA_DEV void wv_join2(A&, unsigned&) {}
 ZSA_DEV unsigned long long wv_clock() { return 0; }
 ZSA_DEV unsigned wv_atomic_add_lds(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 ZSA_DEV unsigned wv_atomic_or_lds(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }

@@ -593,42 +593,54 @@ ZSA_DEVFN void zsa_parse_chunk(const ZsaTabFilt Tin, u32* ringWords, const ZsaPa
     u32 ip0 = wv_uniform(st.ip0), anchor = wv_uniform(st.anchor), rep1 = wv_uniform(st.rep1), rep2 = wv_uniform(st.rep2), nbSeq = wv_uniform(st.nbSeq);
     u32 chk = wv_uniform(st.chkRep2), mid = wv_uniform(st.midEpisode);
     u32 nextStep = mid ? wv_uniform(st.nextStep) : ip0 + 128;
+#ifdef ZSA_PARSE_PROF
+    u64 pT = wv_uniform64(((ZsaEncShared*)ringWords)->profLast), pAcc[4] = { 0, 0, 0, 0 };          // rest / set-up / events in the ring / events with an older candidate
+#define ZSA_CPROF(i) do { u64 const t_ = wv_clock(); pAcc[i] += t_ - pT; pT = t_; } while (0)
+#else
+#define ZSA_CPROF(i) do {} while (0)
+#endif
     u32* const tabP = T.p;
-    // the lanes of a chunk whose 4 bytes equal the 4 bytes `off` behind them; lanes below `from` are never asked (their
-    // positions lie behind the parse) and may hold anything
-#define ZSA_REPMASK(off, from, OUT) do { \
-        u32 const a_ = winB + (u32)lane - 2 - (off); \
-        u32 rv_ = zsa_ring32(R, a_);                                 /* masked ring address, always legal */ \
-        if (winB + (from) - 2 - (off) < R.lo) {                      /* uniform: older than the ring (in the block: chunks start at or below safeEnd) */ \
-            bool const need_ = (u32)lane >= (from);                  /* (no per-lane branch: the other lanes read the first needed address) */ \
-            rv_ = wv_ldg32_now(R.src + (need_ ? a_ : winB + (from) - 2 - (off))); \
-            if (!need_) rv_ = ~(u32)wv64; \
-        } \
-        OUT = wv_ballot(rv_ == (u32)wv64); } while (0)
+    u64* seqP = seqOut + nbSeq;                             // where the next sequence goes
+    u32 const vz = wv_vzero();                              // a zero the compiler cannot see through: what is or-ed with it is computed by the lanes
     for (;;) {   // one chunk per iteration
         if (nextStep - ip0 <= 6 || ip0 > safeEnd) break;        // the step is about to grow (:322-327), or the block ends
         {   u32 const want = ip0 - 2 + 1024;
             if (R.hi < want && R.hi < R.limit) { R.hi = wv_uniform(zsa_ring_fill_far(R.b, R.src, R.hi, want, R.limit)); if (R.hi - R.lo > ZSA_RING_BYTES) R.lo = R.hi - ZSA_RING_BYTES; }
         }
         ZSA_STAT(0);
-        // ---- set-up: lane k <-> position winB + k
+        ZSA_CPROF(0);
+        // ---- set-up: lane k <-> position winB + k.  Memory accesses are issued as early as their addresses are known and
+        // consumed late, so that the set-up costs one LDS chain (source word -> filter) and ONE trip to global memory (the
+        // cells, and the words behind offsets that reach below the ring), not one trip per item.
         u32 const winB = ip0;
         u32 const q = winB + (u32)lane;
         u64 const wv64 = zsa_ring64(R, q - 2);                  // source word
+        // the 4 bytes rep1 / rep2 behind every lane (masks M1 / M2 below): ring addresses are masked, always legal
+        u32 rv1 = zsa_ring32(R, q - 2 - rep1), rv2 = zsa_ring32(R, q - 2 - rep2);
+        bool const far1 = rep1 != 0 && winB - 2 - rep1 < R.lo, far2 = rep2 != 0 && winB - 2 - rep2 < R.lo;   // uniform: older than the ring
+        if (far1) rv1 = wv_ldg32(R.src + (q - 2 - rep1));       // (in the block: chunks start at or below safeEnd, offsets reach no lower than the prefix)
+        if (far2) rv2 = wv_ldg32(R.src + (q - 2 - rep2));
         u32 const whash = zsa_hashT<MLS>(wv64, hlog);           // cell number
         u32 const wcell = (ZSA_FPV(wv64) << posBits) | q;       // the lane's own cell value
         u32 const wnib = T.fget(whash);                         // filter bits of the cell at set-up
-        u64 H = wv_ballot(wnib == T.top(wcell));                // lanes whose probe passes the filter
+        u32* const dw = T.dupWord(whash);
+        u32 const bit = 1u << (whash & 31u);
+        u32 const dprev = wv_atomic_or_lds(dw, bit);            // (shared-cell detection, continued below)
+        // The table does not change while the chunk is scanned (commits are deferred), so the cells are fetched here, once per
+        // chunk and for all lanes that pass the filter at the same time, instead of once per event in the event's own
+        // dependency chain: a cell gives the candidate's position and the fingerprint bits the filter does not hold, and
+        // H keeps the lanes whose whole fingerprint agrees.
+        bool const pass = wnib == T.top(wcell);                 // the probe passes the filter
+        u32 cell = 0;
+        if (pass) cell = wv_ldg_cell(tabP + whash);
         // lanes that share their cell with another lane: the first lane to reach a cell's bit finds it clear, the
         // others find it set and clear it again, which tells the first one
         u32 winValid;
-        {   u32* const dw = T.dupWord(whash);
-            u32 const bit = 1u << (whash & 31u);
-            bool const late = (wv_atomic_or_lds(dw, bit) & bit) != 0;
+        {   bool const late = (dprev & bit) != 0;
             wv_lds_fence();
-            if (late) (void)wv_atomic_and_lds(dw, ~bit);
+            (void)wv_atomic_and_lds(dw, late ? ~bit : 0xFFFFFFFFu);
             wv_lds_fence();
-            bool const shares = late || !(*dw & bit);
+            bool const shares = late | ((*dw & bit) == 0);
             wv_lds_fence();
             *dw = 0;
             wv_lds_fence();
@@ -638,47 +650,43 @@ ZSA_DEVFN void zsa_parse_chunk(const ZsaTabFilt Tin, u32* ringWords, const ZsaPa
         }
         if (winValid < 2) { *backoff = ip0 + 96; ZSA_STAT(4); break; }   // (lanes 0 and 1 share a cell: runs of equal bytes)
         u32 const winEnd = winB + (winValid < 63 ? winValid : 63u);
-        // The table does not change while the chunk is scanned (commits are deferred), so the cells are fetched here, once per
-        // chunk and for all lanes that pass the filter at the same time, instead of once per event in the event's own
-        // dependency chain: a cell gives the candidate's position and the fingerprint bits the filter does not hold, and
-        // H keeps the lanes whose whole fingerprint agrees.  (Measured: fetching the candidates' bytes here as well --
-        // 8 on either side, so that short matches need no memory at all -- adds nothing on top of this.)
         u32 wcand;                                              // per lane with a table hit: the candidate's position
-        {   bool const probe = ((H >> lane) & 1) != 0 && (u32)lane < winValid;
-            u32 cx = 1u << posBits;
-            if (probe) cx = wv_ldg_cell(tabP + whash) ^ wcell;
+        u64 H;                                                  // lanes with a table hit
+        {   u32 const cx = pass ? cell ^ wcell : 1u << posBits;
             wcand = (cx & posMask) ^ q;                                      // (the low bits of wcell are q)
-            H = wv_ballot((cx >> posBits) == 0 && wcand >= prefixStartIndex);
+            H = wv_ballot((cx >> posBits) == 0 && wcand >= prefixStartIndex && (u32)lane < winValid);
         }
-        u64 M1 = 0, M2 = 0;
-        if (rep1) ZSA_REPMASK(rep1, 0u, M1);
-        if (rep2) ZSA_REPMASK(rep2, 0u, M2);
+        u64 const M1s = wv_ballot(rv1 == (u32)wv64), M2s = wv_ballot(rv2 == (u32)wv64);
+        u64 M1 = rep1 ? M1s : 0, M2 = rep2 ? M2s : 0;
         u64 M2c = chk ? M2 : 0;                                 // M2 where the immediate-repcode check is due: after an event (not at a search that continues)
         u32 limEnd = winEnd < nextStep - 3 ? winEnd : nextStep - 3;   // pairs are decided here while both lanes lie below winEnd and the step stays 2
         u32 insV = 0;                                           // per lane: the position entered the table since set-up (not yet written)
         u32 lateA = 0, lateB = 0;                               // positions beyond the chunk that enter the table after what is pending
+        ZSA_CPROF(1);
         // ---- the events of the chunk, in the reference's order: the immediate repcode at ip0 (zstd_fast.c:311-324), then per
         // pair the repcode check at ip0 + 2i + 2 and the two table checks
         for (;;) {
             u32 const o = ip0 - winB;
-            u32 kind, cur, m, four, eBack, cnt;                 // kind 0: immediate repcode, 1: repcode at a pair's ip2, 2: table
-            if (((M2c >> o) & 1ull) != 0) { kind = 0; cur = ip0; m = ip0 - rep2; four = 4; eBack = 0; cnt = 1; }
+            // kind 0: immediate repcode, 1: repcode at a pair's ip2, 2: table.  cnt: positions from ip0 on that enter the table with
+            // the event; pA: the first of the two positions that follow the match into the table (0: none); offBase: as stored
+            u32 kind, cur, m, four, eBack, cnt, pA, pBmask, offBase;
+            if (((M2c >> o) & 1ull) != 0) { kind = 0; cur = ip0; m = ip0 - rep2; four = 4; eBack = 0; cnt = 1; pA = 0; pBmask = 0; offBase = 1; }
             else {
                 u32 const lim = (limEnd - ip0) & ~1u;           // twice the number of pairs decided here, >= 2
-                u64 const Hs = H >> o;
-                u32 fh = Hs ? (u32)__builtin_ctzll(Hs) : 64u;
+                u32 fh = wv_ff1_64(H >> o);                                                            // first table hit (none: 0xFFFFFFFF)
                 if (fh >= lim) fh = 64;
-                u64 const Rs = (M1 >> o) & 0x5555555555555554ull;
-                u32 fr = Rs ? (u32)__builtin_ctzll(Rs) : 64u;
-                if (fr > lim) fr = 64;
-                if (fr != 64 && fr <= fh + 2) { kind = 1; cur = ip0 + fr; m = cur - rep1; four = 4; eBack = 1; cnt = fr; }
+                u32 fr = wv_ff1_64((M1 >> o) & 0x5555555555555554ull);                                 // first repcode hit at an ip2
+                if (fr > lim) fr = 128;
+                if (fr <= fh + 2) { kind = 1; cur = ip0 + fr; m = cur - rep1; four = 4; eBack = 1; cnt = fr; pA = cur; pBmask = 0xFFFFFFFFu; offBase = 1; }
                 else if (fh != 64) {
-                    kind = 2; cur = ip0 + fh; four = 0; cnt = fh + 2;
+                    kind = 2; cur = ip0 + fh; four = 0; cnt = fh + 2; pA = cur + 2; pBmask = 0xFFFFFFFFu;
                     m = wv_readlane(wcand, (int)(o + fh));      // the candidate position was fetched when the chunk was set up
+                    offBase = cur - m + 3;
                     u32 const ba = cur - anchor, bb = m - prefixStartIndex;
                     eBack = ba < bb ? ba : bb;
                 } else {   // no event: all pairs enter the table, the search goes on behind the chunk
                     ZSA_STAT(2);
+                    wv_cold();
                     insV |= (u32)((u32)lane - o < lim);
                     ip0 += lim;
                     mid = 1; chk = 0;
@@ -700,20 +708,21 @@ ZSA_DEVFN void zsa_parse_chunk(const ZsaTabFilt Tin, u32* ringWords, const ZsaPa
                 u32 rv = zsa_ring32(R, q - 2 - off);
                 u64 sb;
                 if (m - 2 >= R.lo + 16) sb = zsa_ring64(R, b);               // uniform: the candidate lies in the ring as well
-                else {   // (no per-lane branches in this loop: lanes that take no part read the candidate's first bytes)
-                    bool const need = fw | ((lane >= 48) & (k < eBack));
-                    sb = wv_ldg64_now(R.src + (need ? b : m + four - 2));
-                    if (!need) sb = ~sa;
-                    if (m - 2 < R.lo) {
-                        bool const needR = (u32)lane >= L;
-                        rv = wv_ldg32_now(R.src + (needR ? q : cur) - 2 - off);
-                        if (!needR) rv = ~(u32)wv64;
-                    }
+                else {   // one trip to global memory for both items (no per-lane branches in this loop: lanes that take no part
+                         // read the first needed address)
+                    bool const need = fw | ((lane >= 48) & (k < eBack)), needR = (u32)lane >= L;
+                    u64 g64 = wv_ldg64(R.src + (need ? b : m + four - 2));
+                    u32 g32 = wv_ldg32(R.src + (needR ? q : cur) - 2 - off);
+                    wv_join2(g64, g32);
+                    sb = need ? g64 : ~sa;
+                    rv = needR ? g32 : ~(u32)wv64;
                 }
                 u64 const diff = sa ^ sb;
                 u32 const eq = diff ? ((u32)__builtin_ctzll(diff) >> 3) : 8;
-                bool const stop = (fw & (eq < 8)) | ((!fw) & ((k >= eBack) | (eq == 0)));     // (bitwise: no per-lane branch)
-                u64 const sbal = wv_ballot(stop);
+                // a lane stops the count when fewer than `thr` of its bytes agree: 8 forwards; backwards 1 (its byte) within
+                // eBack and 9 (always) beyond it.  (Lanes 16..47 are not looked at.)
+                u32 const thr = fw ? 8u : (k < eBack ? 1u : 9u);
+                u64 const sbal = wv_ballot(eq < thr);
                 Mn = wv_ballot(rv == (u32)wv64);
                 u32 const sf = (u32)sbal & 0xFFFFu, sk = (u32)(sbal >> 48);
                 if (sf) { int const f = __builtin_ctz(sf); fwd = 8u * (u32)f + wv_readlane(eq, f); }
@@ -721,36 +730,34 @@ ZSA_DEVFN void zsa_parse_chunk(const ZsaTabFilt Tin, u32* ringWords, const ZsaPa
                 if (sk) bwd = (u32)__builtin_ctz(sk);
                 else bwd = wv_uniform(zsa_back_far(R.b, R.src, R.lo, R.hi, R.limit, cur - 2, m - 2, eBack));
             }
+            ZSA_CPROF((m - 2 >= R.lo + 16) ? 2 : 3);
             if (kind == 2 && fwd < 4) { ZSA_STAT(6); H &= ~(1ull << L); continue; }   // the fingerprint let it through, the bytes differ: not an event
-            ZSA_STAT(kind == 0 ? 1 : 3);
-            u32 const start = cur - bwd, mLength = four + bwd + fwd;
-            {   // (packed by the lanes: the vector unit has the spare issue slots here)
-                u32 const vz = (u32)lane & 0u;
-                u64 const sq = zsa_packseq((start - anchor) | vz, (mLength - ZSA_MINMATCH) | vz, (kind == 2 ? off + 3u : 1u) | vz);   // (an immediate repcode starts at the anchor)
-                wv_stg64(seqOut + nbSeq, sq);                              // (every lane, same address, same value: no per-lane branch in this loop)
-            }
-            nbSeq++;
-            ip0 = start + mLength;
-            // positions that enter the table (:266, :278, :300-303): up to the event's pair, plus the next pair's first position
-            // when the second table check hit (step <= 4); an immediate repcode enters its own position (:318).  Then
-            // (:307-309) current0 + 2 and ip0 - 2, in this order.
-            {   u32 lA = 64u, lB = 64u;
-                if (ip0 <= ilimit && kind != 0) {
-                    u32 const pA = cur + (kind == 2 ? 2u : 0u), pB = ip0 - 2;
-                    lA = pA - winB; lB = pB - winB;
-                    if (lB >= 64) { lateB = pB; if (lA >= 64) lateA = pA; }
+            {
+                ZSA_STAT(kind == 0 ? 1 : 3);
+                u32 const start = cur - bwd, mLength = four + bwd + fwd;
+                // (packed by the lanes -- the vector unit has the spare issue slots here -- and stored by every lane, same address,
+                // same value: no per-lane branch in this loop)
+                wv_stg64(seqP, zsa_packseq((start - anchor) | vz, (mLength - ZSA_MINMATCH) | vz, offBase | vz));   // (an immediate repcode starts at the anchor)
+                seqP++;
+                // positions that enter the table (:266, :278, :300-303): up to the event's pair, plus the next pair's first position
+                // when the second table check hit (step <= 4); an immediate repcode enters its own position (:318).  Then
+                // (:307-309) current0 + 2 and ip0 - 2, in this order.
+                u32 const ipOld = ip0;
+                ip0 = start + mLength;
+                u32 pB = (ip0 - 2) & pBmask;
+                if (ip0 > ilimit) { pA = 0; pB = 0; }
+                insV |= (u32)((q - ipOld < cnt) | (q == pA) | (q == pB));
+                // offsets and their masks: the event's offset comes first; a repcode at ip2 keeps the second one
+                if (kind != 1) { rep2 = rep1; M2 = M1; }
+                rep1 = off; M1 = Mn; M2c = M2;
+                anchor = ip0;
+                limEnd = winEnd; nextStep = ip0 + 128;          // (the step stays 2 for 128 bytes from here)
+                if (ip0 + 2 > winEnd) {                         // no pair of the chunk is left to decide
+                    wv_cold();
+                    if (pB > winB + 63) { lateB = pB; if (pA > winB + 63) lateA = pA; }   // (only an event that ends the chunk reaches beyond it)
+                    mid = 0; chk = (ip0 <= ilimit && rep2 != 0) ? 1u : 0u;
+                    break;
                 }
-                insV |= (u32)(((u32)lane - o < cnt) | ((u32)lane == lA) | ((u32)lane == lB));
-            }
-            // offsets and their masks: the event's offset comes first; a repcode at ip2 keeps the second one
-            if (kind != 1) { rep2 = rep1; M2 = M1; }
-            rep1 = off; M1 = Mn; M2c = M2;
-            anchor = ip0;
-            limEnd = winEnd; nextStep = ip0 + 128;              // (the step stays 2 for 128 bytes from here)
-            if (ip0 + 2 > winEnd) {                             // no pair of the chunk is left to decide
-                mid = 0;
-                chk = (ip0 <= ilimit && rep2 != 0) ? 1u : 0u;
-                break;
             }
         }
         // ---- write the positions that entered the table since the chunk was set up.  Lanes below winValid fall into
@@ -776,7 +783,14 @@ ZSA_DEVFN void zsa_parse_chunk(const ZsaTabFilt Tin, u32* ringWords, const ZsaPa
             wv_lds_fence();
         }
     }
-#undef ZSA_REPMASK
+#ifdef ZSA_PARSE_PROF
+    {   ZsaEncShared* const S_ = (ZsaEncShared*)ringWords;   // (the ring is the first member)
+        ZSA_CPROF(0);
+        if (lane == 0) { S_->prof[1] += pAcc[0]; S_->prof[8] += pAcc[1]; S_->prof[9] += pAcc[2]; S_->prof[10] += pAcc[3]; S_->profLast = pT; }
+    }
+#endif
+#undef ZSA_CPROF
+    nbSeq = (u32)(seqP - seqOut);
     st.ip0 = ip0; st.anchor = anchor; st.rep1 = rep1; st.rep2 = rep2; st.nbSeq = nbSeq; st.chkRep2 = chk;
     st.midEpisode = mid; st.nextStep = nextStep; st.rlo = R.lo; st.rhi = R.hi; st.done = 0;
 }

@@ -46,6 +46,12 @@ ZSA_DEV unsigned long long wv_ldg64(const unsigned char* p) { return ((const __a
 // uniform inputs, so the compiler scalarises them -- and a scalarised chain has to pull every loaded value into SGPRs
 // (v_readfirstlane) right behind its load, i.e. wait for it at once.  Seeding such a section's position with this zero
 // keeps its state in VGPRs, where loads can stay in flight until their first real use.
+// index of the lowest set bit of a wave-uniform 64-bit value, 0xFFFFFFFF for zero: s_ff1_i32_b64 as it is (the compiler's own
+// lowering of "ctz, or a constant for zero" adds a compare and a select)
+ZSA_DEV unsigned wv_ff1_64(unsigned long long x) { unsigned r; asm("s_ff1_i32_b64 %0, %1" : "=s"(r) : "s"(x)); return r; }
+// Keeps the block it stands in a block of its own: the compiler may not turn the branch around it into selects that every
+// pass of the enclosing loop would then pay for (used on loop exits that carry bookkeeping).
+ZSA_DEV void wv_cold() { asm volatile(""); }
 ZSA_DEV unsigned wv_vzero() { unsigned z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); return z; }
 // aligned table cells in global memory
 ZSA_DEV unsigned wv_ldg_cell(const unsigned* p) { return *(const __attribute__((address_space(1))) unsigned*)p; }
@@ -64,6 +70,7 @@ ZSA_DEV unsigned long long wv_ldg64_now(const unsigned char* p) { unsigned long 
 // Loads issued together, consumed together: pins the point where all of the given loaded values must have arrived, so the
 // compiler cannot sink each load into the branch that uses it (which would turn one memory round trip into several).
 template <typename A> ZSA_DEV void wv_join(A& a, unsigned& b, unsigned& c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); }
+template <typename A> ZSA_DEV void wv_join2(A& a, unsigned& b) { asm volatile("" : "+v"(a), "+v"(b)); }
 ZSA_DEV unsigned long long wv_clock() { return (unsigned long long)clock64(); }
 ZSA_DEV unsigned wv_atomic_add_lds(unsigned* p, unsigned v) { return atomicAdd(p, v); }
 ZSA_DEV unsigned wv_atomic_or_lds(unsigned* p, unsigned v) { return atomicOr(p, v); }
