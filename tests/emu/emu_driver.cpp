@@ -4,6 +4,7 @@
 #define ZSA_WAVE_HEADER "zsa_wave_emu.h"
 extern "C" { unsigned long long g_zsa_stat[16]; }
 #define ZSA_STAT(i) do { if (lane == 0) g_zsa_stat[i]++; } while (0)
+#define ZSA_STAT_BYTES 1
 #include "zsa_common.h"
 #include "zsa_decode.h"
 #ifdef ZSA_EMU_ENCODE

@@ -594,7 +594,7 @@ ZSA_DEVFN void zsa_parse_chunk(const ZsaTabFilt Tin, u32* ringWords, const ZsaPa
     u32 chk = wv_uniform(st.chkRep2), mid = wv_uniform(st.midEpisode);
     u32 nextStep = mid ? wv_uniform(st.nextStep) : ip0 + 128;
 #ifdef ZSA_PARSE_PROF
-    u64 pT = wv_uniform64(((ZsaEncShared*)ringWords)->profLast), pAcc[4] = { 0, 0, 0, 0 };          // rest / set-up / events in the ring / events with an older candidate
+    u64 pT = wv_uniform64(((ZsaEncShared*)ringWords)->profLast), pAcc[6] = { 0, 0, 0, 0, 0, 0 };          // rest / set-up / events in the ring / events with an older candidate
 #define ZSA_CPROF(i) do { u64 const t_ = wv_clock(); pAcc[i] += t_ - pT; pT = t_; } while (0)
 #else
 #define ZSA_CPROF(i) do {} while (0)
@@ -604,11 +604,12 @@ ZSA_DEVFN void zsa_parse_chunk(const ZsaTabFilt Tin, u32* ringWords, const ZsaPa
     u32 const vz = wv_vzero();                              // a zero the compiler cannot see through: what is or-ed with it is computed by the lanes
     for (;;) {   // one chunk per iteration
         if (nextStep - ip0 <= 6 || ip0 > safeEnd) break;        // the step is about to grow (:322-327), or the block ends
+        ZSA_CPROF(0);
         {   u32 const want = ip0 - 2 + 1024;
             if (R.hi < want && R.hi < R.limit) { R.hi = wv_uniform(zsa_ring_fill_far(R.b, R.src, R.hi, want, R.limit)); if (R.hi - R.lo > ZSA_RING_BYTES) R.lo = R.hi - ZSA_RING_BYTES; }
         }
         ZSA_STAT(0);
-        ZSA_CPROF(0);
+        ZSA_CPROF(5);
         // ---- set-up: lane k <-> position winB + k.  Memory accesses are issued as early as their addresses are known and
         // consumed late, so that the set-up costs one LDS chain (source word -> filter) and ONE trip to global memory (the
         // cells, and the words behind offsets that reach below the ring), not one trip per item.
@@ -648,7 +649,7 @@ ZSA_DEVFN void zsa_parse_chunk(const ZsaTabFilt Tin, u32* ringWords, const ZsaPa
             u64 const G2 = G & (G - 1);
             winValid = G2 ? (u32)__builtin_ctzll(G2) : 64u;     // lanes [0, winValid) have exact probes
         }
-        if (winValid < 2) { *backoff = ip0 + 96; ZSA_STAT(4); break; }   // (lanes 0 and 1 share a cell: runs of equal bytes)
+        if (winValid < 2) { *backoff = ip0 + 1; ZSA_STAT(4); break; }   // (lanes 0 and 1 share a cell: runs of equal bytes)
         u32 const winEnd = winB + (winValid < 63 ? winValid : 63u);
         u32 wcand;                                              // per lane with a table hit: the candidate's position
         u64 H;                                                  // lanes with a table hit
@@ -760,6 +761,7 @@ ZSA_DEVFN void zsa_parse_chunk(const ZsaTabFilt Tin, u32* ringWords, const ZsaPa
                 }
             }
         }
+        ZSA_CPROF(0);
         // ---- write the positions that entered the table since the chunk was set up.  Lanes below winValid fall into
         // distinct cells that nothing else has written since; the few beyond it follow one by one, in position order
         // (== time order), then the (at most two) positions beyond the chunk
@@ -782,11 +784,12 @@ ZSA_DEVFN void zsa_parse_chunk(const ZsaTabFilt Tin, u32* ringWords, const ZsaPa
             if (lane == 1) { wv_stg_cell(tabP + hh, cell); u32 const d = T.fget(hh) ^ T.top(cell); if (d) T.fxor(hh, d); }
             wv_lds_fence();
         }
+        ZSA_CPROF(4);
     }
 #ifdef ZSA_PARSE_PROF
     {   ZsaEncShared* const S_ = (ZsaEncShared*)ringWords;   // (the ring is the first member)
         ZSA_CPROF(0);
-        if (lane == 0) { S_->prof[1] += pAcc[0]; S_->prof[8] += pAcc[1]; S_->prof[9] += pAcc[2]; S_->prof[10] += pAcc[3]; S_->profLast = pT; }
+        if (lane == 0) { S_->prof[1] += pAcc[0]; S_->prof[8] += pAcc[1]; S_->prof[9] += pAcc[2]; S_->prof[10] += pAcc[3]; S_->prof[7] += pAcc[4]; S_->prof[11] += pAcc[5]; S_->profLast = pT; }
     }
 #endif
 #undef ZSA_CPROF
@@ -835,7 +838,15 @@ ZSA_DEV u32 zsa_parse_fast_blockT(u32* T, u32* filt, u32* dup, u32* ringWords, u
             if (st.ip0 >= backoff) zsa_parse_chunk<MLS>(tab, ringWords, &C, &st, &backoff);
             // whatever stopped the chunk path: the general evaluation takes the parse to the next search restart (or past
             // a stretch where neighbouring positions share cells)
+#ifdef ZSA_STAT_BYTES
+            u32 const g0_ = st.ip0;
+#endif
+            ZSA_PPROF((ZsaEncShared*)ringWords, lane, 1);
             zsa_parse_general<MLS, ZsaTabFilt>(tab, ringWords, (u8*)dup, &C, &st, backoff > st.ip0 ? backoff : 0u);
+            ZSA_PPROF((ZsaEncShared*)ringWords, lane, 0);
+#ifdef ZSA_STAT_BYTES
+            if (lane == 0) { g_zsa_stat[8] += st.ip0 - g0_; g_zsa_stat[9]++; }
+#endif
             if (wv_uniform(st.done)) break;
         }
     } else {
