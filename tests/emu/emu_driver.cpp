@@ -2,9 +2,8 @@
 // Built by tests/emu/Makefile into tests/emu/libzsa_emu.so and driven from tests/test_emu_*.py.
 // Never part of the product; the product library has no CPU path.
 #define ZSA_WAVE_HEADER "zsa_wave_emu.h"
-extern "C" { unsigned long long g_zsa_stat[16]; }
+extern "C" { unsigned long long g_zsa_stat[8]; }
 #define ZSA_STAT(i) do { if (lane == 0) g_zsa_stat[i]++; } while (0)
-#define ZSA_STAT_BYTES 1
 #include "zsa_common.h"
 #include "zsa_decode.h"
 #ifdef ZSA_EMU_ENCODE

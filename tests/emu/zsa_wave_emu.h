@@ -88,6 +88,7 @@ ZSA_DEV unsigned long long wv_ldg64(const unsigned char* p) { unsigned long long
 ZSA_DEV unsigned wv_vzero() { return 0; }
 ZSA_DEV unsigned wv_ff1_64(unsigned long long x) { return x ? (unsigned)__builtin_ctzll(x) : 0xFFFFFFFFu; }
 ZSA_DEV void wv_cold() {}
+ZSA_DEV void wv_keep(unsigned) {}
 ZSA_DEV unsigned wv_ldg_cell(const unsigned* p) { return *p; }
 ZSA_DEV void wv_stg_cell(unsigned* p, unsigned v) { *p = v; }
 ZSA_DEV void wv_stg64(void* p, unsigned long long v) { *(unsigned long long*)p = v; }

@@ -838,15 +838,9 @@ ZSA_DEV u32 zsa_parse_fast_blockT(u32* T, u32* filt, u32* dup, u32* ringWords, u
             if (st.ip0 >= backoff) zsa_parse_chunk<MLS>(tab, ringWords, &C, &st, &backoff);
             // whatever stopped the chunk path: the general evaluation takes the parse to the next search restart (or past
             // a stretch where neighbouring positions share cells)
-#ifdef ZSA_STAT_BYTES
-            u32 const g0_ = st.ip0;
-#endif
             ZSA_PPROF((ZsaEncShared*)ringWords, lane, 1);
             zsa_parse_general<MLS, ZsaTabFilt>(tab, ringWords, (u8*)dup, &C, &st, backoff > st.ip0 ? backoff : 0u);
             ZSA_PPROF((ZsaEncShared*)ringWords, lane, 0);
-#ifdef ZSA_STAT_BYTES
-            if (lane == 0) { g_zsa_stat[8] += st.ip0 - g0_; g_zsa_stat[9]++; }
-#endif
             if (wv_uniform(st.done)) break;
         }
     } else {

@@ -52,6 +52,8 @@ ZSA_DEV unsigned wv_ff1_64(unsigned long long x) { unsigned r; asm("s_ff1_i32_b6
 // Keeps the block it stands in a block of its own: the compiler may not turn the branch around it into selects that every
 // pass of the enclosing loop would then pay for (used on loop exits that carry bookkeeping).
 ZSA_DEV void wv_cold() { asm volatile(""); }
+// keeps a loaded value alive up to this point (a load made for its effect on the cache)
+ZSA_DEV void wv_keep(unsigned v) { asm volatile("" :: "v"(v)); }
 ZSA_DEV unsigned wv_vzero() { unsigned z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); return z; }
 // aligned table cells in global memory
 ZSA_DEV unsigned wv_ldg_cell(const unsigned* p) { return *(const __attribute__((address_space(1))) unsigned*)p; }
