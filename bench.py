@@ -117,13 +117,13 @@ def cpu_model():
     return "unknown"
 
 
-def _cpu_run(exe, lib, impl, frame_size, frames, seed, threads, level):
-    out = subprocess.run([exe, lib, impl, "0", str(frame_size), str(frames), str(seed), str(threads), str(level)],
+def _cpu_run(exe, lib, impl, frame_size, frames, seed, threads, level, kind=0):
+    out = subprocess.run([exe, lib, impl, str(kind), str(frame_size), str(frames), str(seed), str(threads), str(level)],
                          capture_output=True, text=True, timeout=600, check=True).stdout
     return json.loads(out.strip().splitlines()[-1])
 
 
-def cpu_baseline(frame_size, n_frames, seed, level):
+def cpu_baseline(frame_size, n_frames, seed, level, kind=0, quick=False):
     """Reference C path (oracle/_ref, libzstd 1.5.5 as vendored by the reference) on the host cores of this box,
     one ZSTD_compress/ZSTD_decompress call per frame from a pthread pool over all the frames of the workload
     (Go is not installed).  Threads = every core this process may run on; the 1-thread figure (on a
@@ -150,16 +150,18 @@ def cpu_baseline(frame_size, n_frames, seed, level):
         tc, td = 1.0 / r["compress_GBps"], 1.0 / r["decompress_GBps"]
         return {"round_trip_GBps": round(1.0 / (tc + td), 4), "compress_GBps": r["compress_GBps"], "decompress_GBps": r["decompress_GBps"]}
     try:
-        full = _cpu_run(exe, lib, impl, frame_size, n_frames, seed, cores, level)
+        full = _cpu_run(exe, lib, impl, frame_size, n_frames, seed, cores, level, kind)
         res = {"value": fold(full)["round_trip_GBps"], "unit": "GB/s", "cores": cores, "kind": kind, "cpu_model": cpu_model(),
                "compress_GBps": full["compress_GBps"], "decompress_GBps": full["decompress_GBps"], "ratio": full["ratio"],
                "libzstd": full["libzstd"],
                "sample": "all %d frames (%d KiB each, same corpus/seed), %d pthreads = every core in sched_getaffinity, one call per frame"
                          % (n_frames, frame_size // 1024, cores)}
-        one = _cpu_run(exe, lib, impl, frame_size, max(1, n_frames // 4), seed, 1, level)
+        if quick:
+            return res
+        one = _cpu_run(exe, lib, impl, frame_size, max(1, n_frames // 4), seed, 1, level, kind)
         res["one_thread"] = dict(fold(one), frames=max(1, n_frames // 4))
         if share != cores:
-            sh = _cpu_run(exe, lib, impl, frame_size, n_frames, seed, share, level)
+            sh = _cpu_run(exe, lib, impl, frame_size, n_frames, seed, share, level, kind)
             res["at_cpu_share"] = dict(fold(sh), threads=share, note="OMP_NUM_THREADS: the CPU share the harness gives one GPU's job")
         return res
     except Exception as e:   # the baseline is a reported number, never a reason to lose the GPU line
@@ -213,6 +215,116 @@ def end_to_end(zstd_amd, host, frame_size, n, level):
             "single_call_compress_us_1KiB": round(single_us, 1)}
 
 
+def _oracle():
+    """The CPU oracle as the CHECKER of sampled frames (never the thing measured); None when it is not built."""
+    opath = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(opath):
+        return None
+    orc = ctypes.CDLL(opath)
+    orc.zo_compress.restype = ctypes.c_size_t
+    orc.zo_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
+    orc.zo_createCDict.restype = ctypes.c_void_p
+    orc.zo_createCDict.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
+    orc.zo_compress_usingCDict.restype = ctypes.c_size_t
+    orc.zo_compress_usingCDict.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p]
+    orc.zo_freeCDict.argtypes = [ctypes.c_void_p]
+    return orc
+
+
+def kernel_of(level, dictionary):
+    """the compress kernel a level resolves to at these frame sizes (clevels.h: ZSTD_fast for levels <= 2, ZSTD_dfast for 3-4, greedy/lazy above)"""
+    if dictionary is not None:
+        return "zsa_k_compress_dict"
+    return "zsa_k_compress" if level < 3 else "zsa_k_compress_dfast" if level < 5 else "zsa_k_compress_lazy"
+
+
+def measure_config(zstd_amd, corpus, torch, dev, stream, kind, fs, n, seed, level, dictionary=None, steps=2, decode_only=False, samples=8):
+    """One BASELINE configuration, device resident: compress all frames, hand the sizes over on the device, decompress;
+    HIP events on the launch stream.  Every entry is checked: all frames decode to the input bit for bit (computed, on the
+    device) and a sample of the compressed frames equals the oracle's bytes."""
+    host = corpus.generate(kind, fs, n, seed, threads=16)
+    src = torch.from_numpy(host).to(dev)
+    bound = zstd_amd.CompressBound(fs)
+    stride = (bound + 255) // 256 * 256
+    cbuf = torch.empty(n * stride, dtype=torch.uint8, device=dev)
+    out = torch.zeros(n * fs, dtype=torch.uint8, device=dev)
+    enc, dec = zstd_amd.DeviceBatch(n), zstd_amd.DeviceBatch(n)
+    enc.set_frames_strided(n, src.data_ptr(), fs, None, cbuf.data_ptr(), stride, bound, stream)
+    dec.set_frames_strided(n, cbuf.data_ptr(), stride, None, out.data_ptr(), fs, fs, stream)
+    bp = zstd_amd.NewBulkProcessor(dictionary, level) if dictionary is not None else None
+    cd, dd = (bp.cDict, bp.dDict) if bp else (None, None)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    tc = td = 0.0
+    for it in range(steps + 1):          # the first pass is the warm-up (and sizes the workspace)
+        ev[0].record(); enc.compress(level, cd, stream); ev[1].record()
+        dec.link_src_sizes(enc, stream); dec.decompress(dd, stream); ev[2].record()
+        torch.cuda.synchronize()
+        if it:
+            tc += ev[0].elapsed_time(ev[1]); td += ev[1].elapsed_time(ev[2])
+    csz, dsz = enc.results(stream), dec.results(stream)
+    ok_c = all(0 < c < 2 ** 63 for c in csz)
+    exact = bool(ok_c and all(d == fs for d in dsz) and torch.equal(src, out))
+    identical = None
+    orc = _oracle()
+    if orc is not None and ok_c:
+        ch = cbuf.cpu().numpy()
+        ocd = orc.zo_createCDict(dictionary, len(dictionary), level) if dictionary is not None else None
+        identical = True
+        for i in range(0, n, max(1, n // samples)):
+            f = host[i * fs:(i + 1) * fs].tobytes()
+            buf = ctypes.create_string_buffer(bound + 1)
+            m = orc.zo_compress_usingCDict(buf, bound, f, fs, ocd) if ocd else orc.zo_compress(buf, bound, f, fs, level)
+            identical = identical and (buf.raw[:m] == ch[i * stride:i * stride + csz[i]].tobytes())
+        if ocd:
+            orc.zo_freeCDict(ocd)
+        del ch
+    tot, csum = float(n) * fs, float(sum(csz)) if ok_c else float("nan")
+    alg = tot + csum                       # SURVEY 8(d): srcSize + cSize per frame, either direction
+    kc, kd = tc / steps / 1e3, td / steps / 1e3
+    r = {"frames": n, "frame_bytes": fs, "corpus": kind, "seed": seed, "level": level,
+         "decompress_GBps": round(tot / kd / 1e9, 3), "ratio": round(tot / csum, 4),
+         "roofline_frac_decompress": round(alg / kd / 1e9 / HBM_PEAK_GBPS, 6), "kernel_decompress": "zsa_k_decompress",
+         "bit_exact_round_trip": exact, "byte_identical_to_oracle_sample": identical}
+    if dictionary is not None:
+        r["dictionary_bytes"] = len(dictionary)
+    if decode_only:
+        r["note"] = "decode-only configuration: frames produced on the device (sample byte-identical to the CPU path), only the decode is the figure"
+    else:
+        r.update({"compress_GBps": round(tot / kc / 1e9, 3), "roofline_frac_compress": round(alg / kc / 1e9 / HBM_PEAK_GBPS, 6),
+                  "kernel_compress": kernel_of(level, dictionary)})
+    del src, cbuf, out, enc, dec
+    torch.cuda.empty_cache()
+    return r
+
+
+def baseline_configs(zstd_amd, corpus, torch, dev, stream, with_cpu):
+    """The other BASELINE.json configurations and the JSON-like corpus at the headline shape, one launch size each (N = 1 only).
+    `value` stays configuration 2; these ride along so that every configuration has a driver-visible figure."""
+    import base64
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "dict_cases.json")))
+    trained = base64.b64decode(g["dicts"]["trained_json_8k"]["b64"])
+    out = {}
+    t0 = time.perf_counter()
+    plan = [("C1_json_64KiB_level1", dict(kind="json", fs=65536, n=16384, seed=1234, level=1)),
+            ("C2_json_128KiB_level1", dict(kind="json", fs=131072, n=8192, seed=1234, level=1)),
+            ("C3_bulk_1KiB_trained_dictionary_level1", dict(kind="json", fs=1024, n=1 << 20, seed=7, level=1, dictionary=trained)),
+            ("C4_decode_256KiB_level1", dict(kind="log", fs=262144, n=8192, seed=43, level=1, decode_only=True)),
+            ("C5_1MiB_chunks_level3_dfast", dict(kind="log", fs=1 << 20, n=4096, seed=44, level=3)),
+            ("log_128KiB_level5_go_default", dict(kind="log", fs=131072, n=8192, seed=42, level=5, steps=1))]
+    for name, kw in plan:
+        try:
+            out[name] = measure_config(zstd_amd, corpus, torch, dev, stream, **kw)
+        except Exception as e:           # a reported extra, never a reason to lose the line
+            out[name] = {"failed": repr(e)}
+    if with_cpu:   # configuration 1 IS the CPU configuration: the reference C on this box's cores, same corpus and framing
+        try:
+            out["C1_json_64KiB_level1"]["cpu_baseline"] = cpu_baseline(65536, 16384, 1234, 1, kind=1, quick=True)
+        except Exception as e:
+            out["C1_json_64KiB_level1"]["cpu_baseline"] = {"failed": repr(e)}
+    out["seconds"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,6 +336,7 @@ def main():
     ap.add_argument("--level", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the block with the other BASELINE.json configurations")
     ap.add_argument("--exchange-dry-run", action="store_true",
                     help="CPU-only rehearsal of the rank plumbing (spawn, shard plan, all-gather of sizes, offsets) over gloo with "
                          "made-up sizes; nothing is compressed and no throughput is printed")
@@ -355,10 +468,16 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     total_c_all = float(last["total"].item())
+    # the flags of the line are computed on what the TIMED steps left behind (every rank; folded below)
+    exact_after = bool(all(d == FS for d in dec.results(stream)) and torch.equal(out, src))
+    agree_after = bool(ranks_agree(last["offsets"], world) and last["gathered"][rank].tolist() == enc.results(stream))
     if world > 1:
         t = torch.tensor([elapsed, t_c, t_d], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, t_c, t_d = [float(x) for x in t.tolist()]
+        f = torch.tensor([1 if exact_after else 0, 1 if agree_after else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        exact_after, agree_after = bool(f[0].item()), bool(f[1].item())
 
     if rank == 0:
         K = args.steps
@@ -370,7 +489,7 @@ def main():
         algo_d = float(total_c) + bytes_rank      #              decompress = cSize + dstSize
         wg, lds = enc.last_launch()
         # the kernel family of the level at this frame size (clevels.h: ZSTD_fast for levels <= 2, ZSTD_dfast for 3-4, greedy/lazy above)
-        kernel_c = "zsa_k_compress" if args.level < 3 else "zsa_k_compress_dfast" if args.level < 5 else "zsa_k_compress_lazy"
+        kernel_c = kernel_of(args.level, None)
         traffic_c, traffic_d, traffic_src = committed_traffic(N, FS, args.level, kernel_c)
         res = {
             "metric": "GB/s compress & decompress round trip (whole job, uncompressed bytes), %d KiB frames, level %d; ratio" % (FS // 1024, args.level),
@@ -387,17 +506,17 @@ def main():
             "compress_GBps": round(bytes_all / (kc_ms / 1e3) / 1e9, 3),
             "decompress_GBps": round(bytes_all / (kd_ms / 1e3) / 1e9, 3),
             "ratio": round(bytes_all / total_c_all, 4),
-            "bit_exact_round_trip": True,
+            "bit_exact_round_trip": exact_after,
             "byte_identical_to_oracle_sample": identical,
-            "global_offsets_agree_on_all_ranks": True,
+            "global_offsets_agree_on_all_ranks": agree_after,
             "build_id": build_id(),
             "roofline": {"bound": "hbm", "kernel": kernel_c, "achieved": round(algo_c / (kc_ms / 1e3) / 1e9, 3),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(algo_c / (kc_ms / 1e3) / 1e9 / HBM_PEAK_GBPS, 6),
-                         "traffic": traffic_c, "traffic_source": traffic_src, "avg_launch_ms": round(kc_ms, 3), "algorithmic_bytes_per_launch": int(algo_c),
+                         "traffic": traffic_c and traffic_c["raw"], "traffic_x2_upper_bound": traffic_c and traffic_c["x2_upper_bound"], "traffic_source": traffic_src, "avg_launch_ms": round(kc_ms, 3), "algorithmic_bytes_per_launch": int(algo_c),
                          "workgroups": wg, "lds_bytes_per_workgroup": lds},
             "roofline_decompress": {"bound": "hbm", "kernel": "zsa_k_decompress", "achieved": round(algo_d / (kd_ms / 1e3) / 1e9, 3),
                                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(algo_d / (kd_ms / 1e3) / 1e9 / HBM_PEAK_GBPS, 6),
-                                    "traffic": traffic_d, "avg_launch_ms": round(kd_ms, 3), "algorithmic_bytes_per_launch": int(algo_d)},
+                                    "traffic": traffic_d and traffic_d["raw"], "traffic_x2_upper_bound": traffic_d and traffic_d["x2_upper_bound"], "avg_launch_ms": round(kd_ms, 3), "algorithmic_bytes_per_launch": int(algo_d)},
         }
         if not args.no_end_to_end:
             try:
@@ -406,6 +525,12 @@ def main():
                 res["end_to_end"] = {"failed": repr(e)}
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(FS, N, args.seed, args.level)
+        if world == 1 and not args.no_configs:
+            del src, cbuf, out
+            torch.cuda.empty_cache()
+            res["configs"] = baseline_configs(zstd_amd, corpus, torch, dev, stream, not args.no_cpu_baseline)
+        elif not args.no_configs:
+            res["configs"] = "reported by the --gpus 1 run only (one launch size per configuration)"
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
@@ -416,7 +541,7 @@ def main():
 # timed run); tools/collect_profiles.sh runs them on this very command and tools/summarize_profiles.py commits the
 # per-launch averages, with the guide's gfx950 correction (FETCH_SIZE counts 128-B requests as 64 B: x2), to this file,
 # stamped with build_id().  A summary taken on another build, workload or kernel is not quoted: traffic is null then.
-PMC_SUMMARY = "profiles/r02_pmc.json"
+PMC_SUMMARY = "profiles/r03_pmc.json"
 
 
 def committed_traffic(n_frames, frame_bytes, level, kernel_c):
@@ -429,8 +554,15 @@ def committed_traffic(n_frames, frame_bytes, level, kernel_c):
     w = pmc.get("workload", {})
     if (w.get("frames"), w.get("frame_bytes"), w.get("level")) != (n_frames, frame_bytes, level):
         return None, None, "%s was collected on another workload" % PMC_SUMMARY
-    get = lambda k: (int(pmc[k]["hbm_traffic_bytes"]) if k in pmc and "hbm_traffic_bytes" in pmc[k] else None)
-    return get(kernel_c), get("zsa_k_decompress"), PMC_SUMMARY + " (separate rocprofv3 --pmc passes of this command and build, per launch)"
+    def get(k):
+        if k not in pmc or "fabric_traffic_bytes_raw" not in pmc[k]:
+            return None
+        return {"raw": int(pmc[k]["fabric_traffic_bytes_raw"]), "x2_upper_bound": int(pmc[k]["fabric_traffic_bytes_x2_upper_bound"])}
+    return get(kernel_c), get("zsa_k_decompress"), (
+        PMC_SUMMARY + ": separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command and build, per launch, KiB -> bytes. "
+        "The counters are L2-miss (fabric) requests, Infinity-Cache hits included, so this bounds HBM traffic from above. `traffic` is the "
+        "raw sum; FETCH_SIZE under-counts wide coalesced reads by 2 on gfx950 (guide), scattered cell reads not, so "
+        "`traffic_x2_upper_bound` doubles the read part as the other bound")
 
 
 if __name__ == "__main__":

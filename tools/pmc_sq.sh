@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/prof; mkdir -p $OUT
 TAG=${1:-sq}
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_WAIT_INST_ANY -d $OUT/${TAG}_sq -o pmc --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} > $OUT/${TAG}_sq.log 2>&1 || { tail -5 $OUT/${TAG}_sq.log; exit 1; }
+timeout -s KILL 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_WAIT_INST_ANY -d $OUT/${TAG}_sq -o pmc --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-configs ${BENCH_ARGS:-} > $OUT/${TAG}_sq.log 2>&1 || { tail -5 $OUT/${TAG}_sq.log; exit 1; }
 python3 - $OUT/${TAG}_sq <<'PY'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)[0]
