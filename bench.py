@@ -170,49 +170,74 @@ def cpu_baseline(frame_size, n_frames, seed, level, kind=0, quick=False):
 
 def end_to_end(zstd_amd, host, frame_size, n, level):
     """PCIe-inclusive rate: the host-buffer entry points (zsa_compress_batch / zsa_decompress_batch) on a bounded
-    sample of the same frames -- pageable host memory in, pageable host memory out.  Reported beside `value`, never
-    instead of it."""
+    sample of the same frames -- once with pageable host memory in and out (what a caller's ordinary buffers are), once
+    with buffers from zsa_host_alloc (page-locked; the GPU reads and writes them in place).  Reported beside `value`,
+    never instead of it."""
     import numpy as np
     from zstd_amd._lib import lib, c_size_p, c_void_pp
     bound = zstd_amd.CompressBound(frame_size)
+    P, S = ctypes.c_void_p * n, ctypes.c_size_t * n
+    cast = lambda a, t: ctypes.cast(a, t)
+
+    def run(src_addr, c_addr, back_addr):
+        srcp = P(*[src_addr + i * frame_size for i in range(n)])
+        srcn = S(*([frame_size] * n))
+        dstp = P(*[c_addr + i * bound for i in range(n)])
+        dstc = S(*([bound] * n))
+        outn = S()
+        best_c = best_d = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            rc = lib.zsa_compress_batch(cast(srcp, c_void_pp), cast(srcn, c_size_p), cast(dstp, c_void_pp), cast(dstc, c_size_p), cast(outn, c_size_p), n, level, None)
+            best_c = min(best_c, time.perf_counter() - t0)
+            assert rc == 0
+        csz = [outn[i] for i in range(n)]
+        assert all(c < 2 ** 63 for c in csz)
+        backp = P(*[back_addr + i * frame_size for i in range(n)])
+        cszA = S(*csz)
+        outd = S()
+        for _ in range(3):
+            t0 = time.perf_counter()
+            rc = lib.zsa_decompress_batch(cast(dstp, c_void_pp), cast(cszA, c_size_p), cast(backp, c_void_pp), cast(srcn, c_size_p), cast(outd, c_size_p), n, None)
+            best_d = min(best_d, time.perf_counter() - t0)
+            assert rc == 0
+        assert all(outd[i] == frame_size for i in range(n))
+        return best_c, best_d
+
+    b = float(n) * frame_size
+    fold = lambda tc, td: {"compress_GBps": round(b / tc / 1e9, 3), "decompress_GBps": round(b / td / 1e9, 3), "round_trip_GBps": round(b / (tc + td) / 1e9, 3)}
     cbuf = np.empty(n * bound, dtype=np.uint8)
     back = np.empty(n * frame_size, dtype=np.uint8)
-    P, S = ctypes.c_void_p * n, ctypes.c_size_t * n
-    srcp = P(*[host.ctypes.data + i * frame_size for i in range(n)])
-    srcn = S(*([frame_size] * n))
-    dstp = P(*[cbuf.ctypes.data + i * bound for i in range(n)])
-    dstc = S(*([bound] * n))
-    outn = S()
-    cast = lambda a, t: ctypes.cast(a, t)
-    best_c = best_d = 1e9
-    for _ in range(3):
-        t0 = time.perf_counter()
-        rc = lib.zsa_compress_batch(cast(srcp, c_void_pp), cast(srcn, c_size_p), cast(dstp, c_void_pp), cast(dstc, c_size_p), cast(outn, c_size_p), n, level, None)
-        best_c = min(best_c, time.perf_counter() - t0)
-        assert rc == 0
-    csz = [outn[i] for i in range(n)]
-    assert all(c < 2 ** 63 for c in csz)
-    backp = P(*[back.ctypes.data + i * frame_size for i in range(n)])
-    cszA = S(*csz)
-    outd = S()
-    for _ in range(3):
-        t0 = time.perf_counter()
-        rc = lib.zsa_decompress_batch(cast(dstp, c_void_pp), cast(cszA, c_size_p), cast(backp, c_void_pp), cast(srcn, c_size_p), cast(outd, c_size_p), n, None)
-        best_d = min(best_d, time.perf_counter() - t0)
-        assert rc == 0
+    best_c, best_d = run(host.ctypes.data, cbuf.ctypes.data, back.ctypes.data)
     assert bool((back == host[:n * frame_size]).all()), "host-batch round trip is not bit-exact"
+    res = fold(best_c, best_d)
+    res["sample"] = "%d of the frames through zsa_compress_batch / zsa_decompress_batch, pageable host buffers, best of 3" % n
+    del cbuf, back
+    # the same sample from / into page-locked buffers of the library (no staging copies)
+    try:
+        lib.zsa_thread_release()
+        hs, hc, hb = lib.zsa_host_alloc(n * frame_size), lib.zsa_host_alloc(n * bound), lib.zsa_host_alloc(n * frame_size)
+        assert hs and hc and hb, "zsa_host_alloc failed"
+        ctypes.memmove(hs, host.ctypes.data, n * frame_size)
+        pc, pd = run(hs, hc, hb)
+        got = np.ctypeslib.as_array(ctypes.cast(hb, ctypes.POINTER(ctypes.c_uint8)), shape=(n * frame_size,))
+        assert bool((got == host[:n * frame_size]).all()), "pinned host-batch round trip is not bit-exact"
+        del got
+        res["pinned_buffers"] = fold(pc, pd)
+        res["pinned_buffers"]["sample"] = "the same frames, payloads and destinations in memory from zsa_host_alloc"
+        for h in (hs, hc, hb):
+            lib.zsa_host_free(h)
+    except Exception as e:
+        res["pinned_buffers"] = {"failed": repr(e)}
     # single-call latency (zstd_bullk_test.go:252 quotes 1.5 us/op for the CPU library on a 92-byte payload)
     small = bytes(host[:1024])
     zstd_amd.CompressLevel(None, small, level)
     t0 = time.perf_counter()
     for _ in range(200):
         zstd_amd.CompressLevel(None, small, level)
-    single_us = (time.perf_counter() - t0) / 200 * 1e6
-    b = float(n) * frame_size
-    return {"compress_GBps": round(b / best_c / 1e9, 3), "decompress_GBps": round(b / best_d / 1e9, 3),
-            "round_trip_GBps": round(b / (best_c + best_d) / 1e9, 3),
-            "sample": "%d of the frames through zsa_compress_batch / zsa_decompress_batch, pageable host buffers, best of 3" % n,
-            "single_call_compress_us_1KiB": round(single_us, 1)}
+    res["single_call_compress_us_1KiB"] = round((time.perf_counter() - t0) / 200 * 1e6, 1)
+    lib.zsa_thread_release()
+    return res
 
 
 def _oracle():

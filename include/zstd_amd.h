@@ -59,7 +59,8 @@ size_t zsa_decompress_usingDDict(void* dst, size_t dstCapacity, const void* src,
  *    batch as a whole could not run (no device, allocation failure).
  *    Go side: CompressBatch / (*BulkProcessor).CompressBatch in INTEGRATION.md.
  *    Batches of 8 MiB and more are staged by helper threads that live for the call (ZSTD_AMD_COPY_THREADS,
- *    default 4, 1 = none; they copy between the caller's buffers and pinned memory and make no HIP calls).
+ *    default 8, 1 = none; they copy between the caller's buffers and pinned memory and make no HIP calls) and run as up
+ *    to four sub-batches on streams of their own, so that upload, kernel and download overlap.
  * ------------------------------------------------------------------------------------------------------- */
 size_t zsa_compress_batch(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCapacity,
                           size_t* outSize, size_t nFrames, int compressionLevel, const zsa_CDict* cdict /* or NULL */);
@@ -75,8 +76,14 @@ size_t zsa_decompress_batch(const void* const* src, const size_t* srcSize, void*
  *    frames, e.g. 0.6 MiB per resident workgroup for 128 KiB level-1 frames).  A batch, the dictionaries used with it and
  *    all device pointers must belong to the HIP device that was current at zsa_batch_create; an enqueue made under
  *    another device returns "Operation not authorized at current processing stage".
- *    Capacity contract (all compress entry points): dstCapacity >= zsa_compressBound(srcSize) -- what every reference
+ *    Capacity contract of the DEVICE-memory entry points: dstCapacity >= zsa_compressBound(srcSize) -- what every reference
  *    call site passes (zstd.go:96-101) -- else "Destination buffer is too small", even where the frame would have fit.
+ *    The HOST-memory entry points (sections 1 and 2) take any capacity, as ZSTD_compress does: the frame is produced in a
+ *    bound-sized device slot and handed over when it fits the caller's buffer, else "Destination buffer is too small".
+ *    Frames whose sizes are linked on the device (zsa_batch_link_src_sizes) are sized for match tables of up to 5 MiB;
+ *    a frame that needs more (levels 7 and up on inputs above 256 KB) gets "Unsupported parameter" in its result word.
+ *    A compress launch whose workspace does not fit half of the device's free memory keeps fewer frames in flight, and an
+ *    allocation that is still refused is tried once more at half that before "Allocation error" is returned.
  * ------------------------------------------------------------------------------------------------------- */
 typedef struct zsa_batch_s zsa_batch;
 zsa_batch* zsa_batch_create(size_t maxFrames);
@@ -120,10 +127,34 @@ size_t zsa_batch_profile(zsa_batch* b, int enable, uint64_t* out, void* stream);
  *    Limits: at most 2^20 frames per call (more: "Parameter is out of bound"); 128 resident workgroups, so throughput
  *    is below a zsa_batch's.  Calls on one GPU share that array: calls that overlap on one GPU race -- serialise them
  *    (one stream, or events).  The launch is asynchronous on `stream`.
+ *    The array's address on a device is looked up once (a runtime query, not a stream operation): by zsa_batch_create,
+ *    zsa_createDDict or zsa_noalloc_prepare on that device, else by the first call itself -- so a caller whose first call
+ *    would fall under graph capture makes one of those three first, outside the capture.
  * ------------------------------------------------------------------------------------------------------- */
 typedef struct { const void* src; void* dst; uint64_t srcSize; uint64_t dstCapacity; } zsa_frame;
 size_t zsa_decompress_frames_noalloc(const zsa_frame* d_frames, uint64_t* d_results, size_t nFrames,
                                      const zsa_DDict* ddict /* or NULL */, void* stream);
+/* resolves the workspace address on the current device (see above); 0 or an error code.  No counterpart in the reference. */
+size_t zsa_noalloc_prepare(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * 5. What a binding needs around the data path.  No counterparts in libzstd (which has no device to lose).
+ * ------------------------------------------------------------------------------------------------------- */
+/* Why the LAST data-path call made on this thread failed, when the cause lies with the engine and not with the caller's
+ * data: 0 = it did not (the returned code, if any, is the answer libzstd would give), 1 = no usable HIP device, 2 = a HIP
+ * runtime call failed, 3 = device / pinned memory could not be allocated, 4 = batch or dictionary used under another device.
+ * The codes returned in those cases ("Error (generic)", "Allocation error : not enough memory", "Operation not authorized
+ * at current processing stage") are ones libzstd's one-shot calls cannot produce for the same arguments, so a binding answers
+ * them with its CPU path: shim/zstd_amd_on.go falls through to the vendored C whenever this is non-zero.  Covers
+ * zsa_compress*, zsa_decompress*, zsa_*_batch, zsa_*_enqueue, zsa_create?Dict, zsa_batch_create, zsa_host_alloc. */
+int zsa_engine_failure(void);
+/* Page-locked host memory.  A large host batch (section 2) whose payloads all lie in such memory is uploaded straight from
+ * it, and a decompress batch whose destinations all lie in it is downloaded straight into it -- one DMA copy per run of
+ * frames that lie one behind the other -- with no staging copy and no helper threads on that side.  The rates are those of
+ * the staged path (PCIe bounds both); what is saved is the host's copy work.  (A Go binding keeps payload slabs in it: C
+ * memory, outside the Go heap.)  zsa_host_alloc returns NULL on failure. */
+void* zsa_host_alloc(size_t bytes);
+void  zsa_host_free(void* p);
 
 /* staging buffers of the single-call / host-batch entry points are per calling thread and released when the thread ends;
  * a long-lived thread can hand them back early.  (libzstd: ZSTD_freeCCtx / ZSTD_freeDCtx, zstd_ctx.go:43-51) */

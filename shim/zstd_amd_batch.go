@@ -90,13 +90,23 @@ func compressBatch(dst, payloads [][]byte, level int, cdict *C.zsa_CDict, engine
 		for i := range payloads {
 			a.set(i, payloads[i], dst[i])
 		}
-		rc := int(C.zsa_compress_batch(a.src, a.srcSize, a.dst, a.dstCap, a.result, C.size_t(n), C.int(level), cdict))
-		if err := getError(rc); err != nil {
-			return nil, nil, err // the batch as a whole could not run (no device, allocation failure)
+		staged := 0
+		for i := range payloads {
+			staged += len(payloads[i])
 		}
+		enter()
+		rc := int(C.zsa_compress_batch(a.src, a.srcSize, a.dst, a.dstCap, a.result, C.size_t(n), C.int(level), cdict))
+		failed := rc < 0 && engineFailed()
+		leave(staged)
 		res := unsafe.Slice(a.result, n)
 		for i := range results {
 			results[i] = int(res[i])
+			if rc < 0 { // the batch as a whole could not run
+				results[i] = rc
+			}
+			if failed { // ... for a reason of the engine's own (device lost, out of device memory): payload by payload on the CPU
+				results[i] = errParameterUnsupported
+			}
 		}
 	} else {
 		for i := range results {
@@ -160,13 +170,23 @@ func decompressBatch(dst, frames [][]byte, ddict *C.zsa_DDict, engine bool, perC
 				a.set(i, frames[i], dst[i])
 			}
 		}
-		rc := int(C.zsa_decompress_batch(a.src, a.srcSize, a.dst, a.dstCap, a.result, C.size_t(n), ddict))
-		if err := getError(rc); err != nil {
-			return nil, nil, err
+		staged := 0
+		for i := range dst {
+			staged += len(dst[i])
 		}
+		enter()
+		rc := int(C.zsa_decompress_batch(a.src, a.srcSize, a.dst, a.dstCap, a.result, C.size_t(n), ddict))
+		failed := rc < 0 && engineFailed()
+		leave(staged)
 		res := unsafe.Slice(a.result, n)
 		for i := range results {
 			results[i] = int(res[i])
+			if rc < 0 {
+				results[i] = rc
+			}
+		}
+		if failed { // the engine could not run the batch (device lost, out of device memory): frame by frame on the CPU
+			engine = false
 		}
 	}
 	for i, r := range results {

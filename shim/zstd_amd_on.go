@@ -12,6 +12,7 @@ package zstd
 import "C"
 import (
 	"encoding/binary"
+	"runtime"
 	"unsafe"
 )
 
@@ -26,6 +27,11 @@ import (
 //   -10 "Unknown frame descriptor"   on a frame that starts with a legacy (v0.1-v0.7) magic number: the vendored
 //                                    build may carry ZSTD_LEGACY_SUPPORT, the engine does not
 //   no usable HIP device             amdUsable is false and the hooks never enter the engine
+//   any engine-side failure          a HIP call that failed, device or pinned memory that could not be had, a thread that
+//                                    changed devices: C.zsa_engine_failure() is non-zero after the call (include/zstd_amd.h
+//                                    section 5).  The code that came with it ("Error (generic)", "Allocation error", "Operation
+//                                    not authorized") is one the reference's CompressLevel / Decompress cannot produce for these
+//                                    arguments (zstd.go:108-128), so the caller never sees it.
 const (
 	errPrefixUnknown        = -10
 	errParameterUnsupported = -40
@@ -49,6 +55,28 @@ func legacyMagic(src []byte) bool {
 	return m == 0xFD2FB51E || (m >= 0xFD2FB522 && m <= 0xFD2FB527)
 }
 
+// engineFailed reports whether the engine call this goroutine's OS thread just made failed for a reason of the engine's
+// own.  The calling goroutine must not have been moved between the call and this query: both run inside one cgo-free
+// stretch of a function that holds runtime.LockOSThread (see enter/leave below).
+func engineFailed() bool { return C.zsa_engine_failure() != 0 }
+
+// enter pins the goroutine to its OS thread for the span of one engine call plus the query that follows it: the engine's
+// failure flag and its staging buffers are per OS thread.
+func enter() { runtime.LockOSThread() }
+
+// leave ends the span.  After a large batch the thread's staging buffers (pinned and device memory sized to that batch)
+// are handed back: Go's OS threads rarely exit, so nothing else would ever release them.
+func leave(stagedBytes int) {
+	if stagedBytes >= releaseStagingAbove {
+		C.zsa_thread_release()
+	}
+	runtime.UnlockOSThread()
+}
+
+// releaseStagingAbove bounds what an idle OS thread keeps: staging of calls below it (single payloads, small batches) is
+// kept for the next call, staging of larger batches is released as the call ends.
+const releaseStagingAbove = 64 << 20
+
 func vendoredCompress(dst, src []byte, level int) int {
 	return int(C.ZSTD_compress(bytesPtr(dst), C.size_t(len(dst)), bytesPtr(src), C.size_t(len(src)), C.int(level)))
 }
@@ -60,8 +88,11 @@ func vendoredDecompress(dst, src []byte) int {
 // hotCompress replaces C.ZSTD_compress at zstd.go:108,115 (and C.ZSTD_compressCCtx at zstd_ctx.go:70,78).
 func hotCompress(dst, src []byte, level int) int {
 	if amdUsable {
+		enter()
 		r := int(C.zsa_compress(bytesPtr(dst), C.size_t(len(dst)), bytesPtr(src), C.size_t(len(src)), C.int(level)))
-		if r != errParameterUnsupported {
+		failed := r < 0 && engineFailed()
+		leave(len(src))
+		if r != errParameterUnsupported && !failed {
 			return r
 		}
 	}
@@ -71,8 +102,11 @@ func hotCompress(dst, src []byte, level int) int {
 // hotDecompress replaces C.ZSTD_decompress at zstd.go:168 (and C.ZSTD_decompressDCtx at zstd_ctx.go:107).
 func hotDecompress(dst, src []byte) int {
 	if amdUsable {
+		enter()
 		r := int(C.zsa_decompress(bytesPtr(dst), C.size_t(len(dst)), bytesPtr(src), C.size_t(len(src))))
-		if !(r == errPrefixUnknown && legacyMagic(src)) {
+		failed := r < 0 && engineFailed()
+		leave(len(dst))
+		if !(r == errPrefixUnknown && legacyMagic(src)) && !failed {
 			return r
 		}
 	}
@@ -112,8 +146,11 @@ func (a *bulkAccel) free() {
 // hotCompressDict replaces the CCtx create / C.ZSTD_compress_usingCDict / free sequence at zstd_bulk.go:71-96.
 func hotCompressDict(p *BulkProcessor, dst, src []byte) int {
 	if p.accel.cDict != nil {
+		enter()
 		r := int(C.zsa_compress_usingCDict(bytesPtr(dst), C.size_t(len(dst)), bytesPtr(src), C.size_t(len(src)), p.accel.cDict))
-		if r != errParameterUnsupported {
+		failed := r < 0 && engineFailed()
+		leave(len(src))
+		if r != errParameterUnsupported && !failed {
 			return r
 		}
 	}
@@ -125,8 +162,11 @@ func hotCompressDict(p *BulkProcessor, dst, src []byte) int {
 // hotDecompressDict replaces the DCtx create / C.ZSTD_decompress_usingDDict / free sequence at zstd_bulk.go:124-132.
 func hotDecompressDict(p *BulkProcessor, dst, src []byte) int {
 	if p.accel.dDict != nil {
+		enter()
 		r := int(C.zsa_decompress_usingDDict(bytesPtr(dst), C.size_t(len(dst)), bytesPtr(src), C.size_t(len(src)), p.accel.dDict))
-		if !(r == errPrefixUnknown && legacyMagic(src)) {
+		failed := r < 0 && engineFailed()
+		leave(len(dst))
+		if !(r == errPrefixUnknown && legacyMagic(src)) && !failed {
 			return r
 		}
 	}

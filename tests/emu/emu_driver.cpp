@@ -176,4 +176,52 @@ extern "C" size_t emu_decompress_ddict(void* dst, size_t cap, const void* src, s
     emu_run_wave(dec_entry, &A);
     return (size_t)A.result;
 }
+
+// ---- pieces of the entropy stage on their own, for tests against the reference's functions of the same name
+// FSE_normalizeCount + FSE_writeNCount: count[0..maxSV] -> norm[0..maxSV], description bytes.  Returns the description's size,
+// 0 when writing failed, (size_t)-1 when the normalisation failed.
+struct NcArgs { ZsaEncShared* S; const unsigned* count; unsigned maxSV, total, tableLog, useLowProb; short* norm; u8* out; size_t result; };
+static void nc_entry(void* a)
+{
+    NcArgs* A = (NcArgs*)a;
+    int const lane = wv_lane();
+    u32* const cnt = A->S->count;
+    for (u32 i = (u32)lane; i < 256; i += ZSA_WAVE) { cnt[i] = i <= A->maxSV ? A->count[i] : 0; A->S->norm[i] = 0; }
+    wv_sync();
+    u32 const bad = zsa_fse_normalizeCount_wave(A->S->norm, A->tableLog, cnt, A->total, A->maxSV, A->useLowProb, lane);
+    wv_sync();
+    size_t r = (size_t)-1;
+    if (!bad) {
+        if ((u32)lane <= A->maxSV) A->norm[lane] = A->S->norm[lane];
+        r = zsa_fse_writeNCount_wave(A->S, A->out, A->S->norm, A->maxSV, A->tableLog, lane);
+    }
+    if (lane == 0) A->result = r;
+}
+extern "C" size_t emu_fse_ncount(const unsigned* count, unsigned maxSV, unsigned total, unsigned tableLog, unsigned useLowProb, short* norm, void* out)
+{
+    static ZsaEncShared S;
+    NcArgs A = { &S, count, maxSV, total, tableLog, useLowProb, norm, (u8*)out, 0 };
+    emu_run_wave(nc_entry, &A);
+    return A.result;
+}
+// HUF_buildCTable_wksp: count[0..maxSV] -> code lengths and values per symbol.  Returns the table's maxNbBits (0: error).
+struct HcArgs { ZsaEncShared* S; const unsigned* count; unsigned maxSV, maxNbBits; u8* nbBits; unsigned short* val; unsigned result; };
+static void hc_entry(void* a)
+{
+    HcArgs* A = (HcArgs*)a;
+    int const lane = wv_lane();
+    for (u32 i = (u32)lane; i < 256; i += ZSA_WAVE) A->S->count[i] = i <= A->maxSV ? A->count[i] : 0;
+    wv_sync();
+    u32 const r = zsa_huf_buildCTable_wave(A->S, &A->S->hufNext, A->S->count, A->maxSV, A->maxNbBits, lane);
+    wv_sync();
+    for (u32 i = (u32)lane; i < 256; i += ZSA_WAVE) { A->nbBits[i] = A->S->hufNext.nbBits[i]; A->val[i] = A->S->hufNext.val[i]; }
+    if (lane == 0) A->result = r;
+}
+extern "C" unsigned emu_huf_ctable(const unsigned* count, unsigned maxSV, unsigned maxNbBits, unsigned char* nbBits, unsigned short* val)
+{
+    static ZsaEncShared S;
+    HcArgs A = { &S, count, maxSV, maxNbBits, nbBits, val, 0 };
+    emu_run_wave(hc_entry, &A);
+    return A.result;
+}
 #endif

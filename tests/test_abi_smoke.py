@@ -9,9 +9,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "tests", "abi_smoke")
 
 
-def _run(*args):
+def _run(*args, env=None):
     assert os.path.exists(BIN), "tests/abi_smoke is missing: run python -c 'import __graft_entry__ as g; g.build()'"
-    r = subprocess.run([BIN, *args], capture_output=True, text=True, timeout=300)
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([BIN, *args], capture_output=True, text=True, timeout=300, env=e)
     assert r.returncode == 0, r.stdout + r.stderr
     return r.stdout
 
@@ -23,6 +25,21 @@ def test_abi_header_only_calls():
 @pytest.mark.gpu
 def test_abi_calls_that_move_data():
     assert "abi_smoke ok (gpu)" in _run("gpu")
+
+
+def test_engine_failure_is_flagged_and_falls_back_without_a_device():
+    """SURVEY 8b "any device error => CPU re-run": with no usable device (this container has none; on a GPU box the child
+    is started with the devices hidden, before it makes any HIP call) every data call fails with a code AND
+    zsa_engine_failure() != 0, which is what the Go hooks test before answering with the vendored C."""
+    out = _run("enginefail", env={"HIP_VISIBLE_DEVICES": "-1", "ROCR_VISIBLE_DEVICES": "-1"})
+    assert out.count("-> vendored C") == 3 and "abi_smoke ok" in out
+
+
+@pytest.mark.gpu
+def test_engine_failure_on_refused_allocations_and_not_on_data_errors():
+    out = _run("enginefail", env={"ZSTD_AMD_FAIL": "alloc"})
+    assert out.count("-> vendored C") == 3
+    assert "data errors are not flagged" in _run("enginefail")
 
 
 def test_shim_binds_only_declared_entry_points():

@@ -532,17 +532,30 @@ def test_many_threads_single_call_api(z, oracle):
 
 
 def test_capacity_contract(z, oracle):
-    """include/zstd_amd.h: dstCapacity >= zsa_compressBound(srcSize) is required; a smaller destination is refused with the
-    reference's "Destination buffer is too small" even where the frame would fit."""
+    """Host entry points: any capacity the frame fits is served, as ZSTD_compress does (zstd.go:95-129 call-site contract;
+    a frame that does not fit gives the reference's "Destination buffer is too small").  Device entry points keep
+    dstCapacity >= zsa_compressBound(srcSize) as their contract (include/zstd_amd.h section 3)."""
+    import torch
     from zstd_amd._lib import lib
     p = b"abcd" * 1000
+    want = oracle.compress(p, 1)
     bound = z.CompressBound(len(p))
     out = ctypes.create_string_buffer(bound)
     src = ctypes.create_string_buffer(p, len(p))
-    r = lib.zsa_compress(ctypes.cast(out, ctypes.c_void_p), bound - 1, ctypes.cast(src, ctypes.c_void_p), len(p), 1)
+    for cap in (bound, bound - 1, len(want) + 1, len(want)):
+        r = lib.zsa_compress(ctypes.cast(out, ctypes.c_void_p), cap, ctypes.cast(src, ctypes.c_void_p), len(p), 1)
+        assert not lib.zsa_isError(r) and out.raw[:r] == want, cap
+    r = lib.zsa_compress(ctypes.cast(out, ctypes.c_void_p), len(want) - 1, ctypes.cast(src, ctypes.c_void_p), len(p), 1)
+    assert lib.zsa_isError(r) and z.IsDstSizeTooSmallError(z.ErrorCode(r - 2 ** 64)) and lib.zsa_engine_failure() == 0
+    # device path: below the bound is refused
+    dsrc = torch.frombuffer(bytearray(p), dtype=torch.uint8).cuda()
+    dout = torch.empty(bound, dtype=torch.uint8, device="cuda")
+    b = z.DeviceBatch(1)
+    b.set_frames(dsrc.data_ptr(), [0], [len(p)], dout.data_ptr(), [0], [bound - 1])
+    b.compress(1)
+    r = b.results()[0]
     assert lib.zsa_isError(r) and z.IsDstSizeTooSmallError(z.ErrorCode(r - 2 ** 64))
-    r = lib.zsa_compress(ctypes.cast(out, ctypes.c_void_p), bound, ctypes.cast(src, ctypes.c_void_p), len(p), 1)
-    assert out.raw[:r] == oracle.compress(p, 1)
+    b.close()
 
 
 def test_level1_chunk_and_general_paths(z, oracle):

@@ -47,6 +47,10 @@ def _load():
         "zsa_batch_export_sizes_i32": (S, [V, V, V]),
         "zsa_decompress_frames_noalloc": (S, [V, V, S, V, V]),
         "zsa_thread_release": (None, []),
+        "zsa_noalloc_prepare": (S, []),
+        "zsa_engine_failure": (I, []),
+        "zsa_host_alloc": (V, [S]),
+        "zsa_host_free": (None, [V]),
         "zsa_batch_last_launch": (None, [V, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]),
         "zsa_batch_profile": (S, [V, I, ctypes.POINTER(ctypes.c_uint64), V]),
         "zsa_getCParams": (I, [I, ctypes.c_ulonglong, S, I, ctypes.POINTER(ctypes.c_uint)]),

@@ -220,8 +220,36 @@ ZSA_DEV u32 zsa_readNCount(s16* norm, u32* maxSVPtr, u32* tableLogPtr, const u8*
     return (bitPos + 7) >> 3;
 }
 
+// The weights' FSE stream (fse_decompress.c:177-237 FSE_decompress_usingDTable_generic, at most 255 weights): two interleaved
+// states, one chain -- lane 0.  Table: S->fseCell.  Returns the number of weights, 0 on error.
+ZSA_DEV u32 zsa_huf_decodeWeights(ZsaDecShared* S, const u8* cSrc, u32 cSrcSize, u32 tableLog)
+{
+    u8* const huffWeight = S->weights;
+    ZsaBitR bitD;
+    if (zsa_br_init(bitD, cSrc, cSrcSize)) return 0;
+    u32 state1 = zsa_br_read(bitD, tableLog); zsa_br_reload(bitD);
+    u32 state2 = zsa_br_read(bitD, tableLog); zsa_br_reload(bitD);
+    u32 op = 0;
+    u32 const omax = 255;
+#define ZSA_FSE_GET(st) do { u32 const c = S->fseCell[st]; huffWeight[op++] = (u8)(c >> 16); st = (c & 0xFFFF) + zsa_br_read(bitD, c >> 24); } while (0)
+    while ((zsa_br_reload(bitD) == ZB_unfinished) & (op + 3 < omax)) {
+        ZSA_FSE_GET(state1); ZSA_FSE_GET(state2); ZSA_FSE_GET(state1); ZSA_FSE_GET(state2);
+    }
+    for (;;) {
+        if (op + 2 > omax) return 0;
+        ZSA_FSE_GET(state1);
+        if (zsa_br_reload(bitD) == ZB_overflow) { ZSA_FSE_GET(state2); break; }
+        if (op + 2 > omax) return 0;
+        ZSA_FSE_GET(state2);
+        if (zsa_br_reload(bitD) == ZB_overflow) { ZSA_FSE_GET(state1); break; }
+    }
+#undef ZSA_FSE_GET
+    return op;
+}
+
 // ------------------------------------------------------------------ Huffman table description (entropy_common.c:244-307)
-// Serial (lane 0).  Fills S->weights, S->rankVal; returns bytes consumed, or 0 with *err set.
+// Serial (one lane): the dictionary digest's reader, and the whole-wave table builder's way out for descriptions that name more
+// than 64 weight values.  Fills S->weights, S->rankVal; returns bytes consumed, or 0 with *err set.
 ZSA_DEV u32 zsa_huf_readStats(ZsaDecShared* S, u32* nbSymbolsPtr, u32* tableLogPtr, const u8* src, u32 srcSize, u32* err)
 {
     u32 weightTotal = 0, iSize, oSize;
@@ -265,29 +293,8 @@ ZSA_DEV u32 zsa_huf_readStats(ZsaDecShared* S, u32* nbSymbolsPtr, u32* tableLogP
                 S->fseCell[u] = (((nextState << nbBits) - tableSize) & 0xFFFF) | (symbol << 16) | (nbBits << 24);
             }
         }
-        {   // fse_decompress.c:177-237 FSE_decompress_usingDTable_generic
-            ZsaBitR bitD;
-            u32 const e = zsa_br_init(bitD, cSrc, cSrcSize);
-            if (e) { *err = e; return 0; }
-            u32 state1 = zsa_br_read(bitD, tableLog); zsa_br_reload(bitD);
-            u32 state2 = zsa_br_read(bitD, tableLog); zsa_br_reload(bitD);
-            u32 op = 0;
-            u32 const omax = 255;
-#define ZSA_FSE_GET(st) do { u32 const c = S->fseCell[st]; huffWeight[op++] = (u8)(c >> 16); st = (c & 0xFFFF) + zsa_br_read(bitD, c >> 24); } while (0)
-            while ((zsa_br_reload(bitD) == ZB_unfinished) & (op + 3 < omax)) {
-                ZSA_FSE_GET(state1); ZSA_FSE_GET(state2); ZSA_FSE_GET(state1); ZSA_FSE_GET(state2);
-            }
-            for (;;) {
-                if (op + 2 > omax) { *err = ZSA_dstSize_tooSmall; return 0; }
-                ZSA_FSE_GET(state1);
-                if (zsa_br_reload(bitD) == ZB_overflow) { ZSA_FSE_GET(state2); break; }
-                if (op + 2 > omax) { *err = ZSA_dstSize_tooSmall; return 0; }
-                ZSA_FSE_GET(state2);
-                if (zsa_br_reload(bitD) == ZB_overflow) { ZSA_FSE_GET(state1); break; }
-            }
-#undef ZSA_FSE_GET
-            oSize = op;
-        }
+        oSize = zsa_huf_decodeWeights(S, cSrc, cSrcSize, tableLog);   // (every failure of the stream reads as corruption to the callers)
+        if (!oSize) { *err = ZSA_corruption_detected; return 0; }
     }
     for (u32 i = 0; i <= ZSA_HUF_TABLELOG_MAX; i++) S->rankVal[i] = 0;
     for (u32 n = 0; n < oSize; n++) {
@@ -309,33 +316,6 @@ ZSA_DEV u32 zsa_huf_readStats(ZsaDecShared* S, u32* nbSymbolsPtr, u32* tableLogP
     if ((S->rankVal[1] < 2) || (S->rankVal[1] & 1)) { *err = ZSA_corruption_detected; return 0; }
     *nbSymbolsPtr = oSize + 1;
     return iSize + 1;
-}
-
-// The weights' FSE stream (fse_decompress.c:177-237 FSE_decompress_usingDTable_generic, at most 255 weights): two interleaved
-// states, one chain -- lane 0.  Table: S->fseCell.  Returns the number of weights, 0 on error.
-ZSA_DEV u32 zsa_huf_decodeWeights(ZsaDecShared* S, const u8* cSrc, u32 cSrcSize, u32 tableLog)
-{
-    u8* const huffWeight = S->weights;
-    ZsaBitR bitD;
-    if (zsa_br_init(bitD, cSrc, cSrcSize)) return 0;
-    u32 state1 = zsa_br_read(bitD, tableLog); zsa_br_reload(bitD);
-    u32 state2 = zsa_br_read(bitD, tableLog); zsa_br_reload(bitD);
-    u32 op = 0;
-    u32 const omax = 255;
-#define ZSA_FSE_GET(st) do { u32 const c = S->fseCell[st]; huffWeight[op++] = (u8)(c >> 16); st = (c & 0xFFFF) + zsa_br_read(bitD, c >> 24); } while (0)
-    while ((zsa_br_reload(bitD) == ZB_unfinished) & (op + 3 < omax)) {
-        ZSA_FSE_GET(state1); ZSA_FSE_GET(state2); ZSA_FSE_GET(state1); ZSA_FSE_GET(state2);
-    }
-    for (;;) {
-        if (op + 2 > omax) return 0;
-        ZSA_FSE_GET(state1);
-        if (zsa_br_reload(bitD) == ZB_overflow) { ZSA_FSE_GET(state2); break; }
-        if (op + 2 > omax) return 0;
-        ZSA_FSE_GET(state2);
-        if (zsa_br_reload(bitD) == ZB_overflow) { ZSA_FSE_GET(state1); break; }
-    }
-#undef ZSA_FSE_GET
-    return op;
 }
 
 // HUF_readStats + HUF_readDTableX1_wksp (entropy_common.c:244-307, huf_decompress.c:358-492) by the whole wave.  Lane 0 reads the

@@ -97,9 +97,10 @@ ZSA_DEV u32 zsa_digest_cdict(ZsaEncShared* SE, ZsaDecShared* SD, const u8* dict,
     if (dictSize < 8) return 0;                     // :4969-4972 nothing is loaded
     u32 contentOff = 0;
     if (zsa_ld32(dict) == ZSA_MAGIC_DICT) {
-        // ---- ZSTD_loadCEntropy, lane 0; tables are built in LDS (SE->ll/of/ml) and copied out by all lanes
+        // ---- ZSTD_loadCEntropy: the descriptions are read by lane 0 (bit-serial), the tables are built by all lanes in LDS
+        // (SE->ll/of/ml) and copied out by all lanes.  SD->u[ZU_tmp]: read position; SD->err: first error
         if (lane == 0) {
-            u32 err = 0, p = 8, ofMaxSV = ZSA_MaxOff, ofRepeatMax = 0;
+            u32 err = 0, p = 8;
             out->hufRepeat = zsa_rep_check;
             {   // huf_compress.c:271-321 HUF_readCTable
                 u32 nbSymbols = 0, tableLog = 0;
@@ -124,30 +125,47 @@ ZSA_DEV u32 zsa_digest_cdict(ZsaEncShared* SE, ZsaDecShared* SD, const u8* dict,
                     p += h;
                 }
             }
-            for (int k = 0; k < 3 && !err; k++) {   // OF, ML, LL (:4848-4888)
-                int const kind = k == 0 ? 1 : (k == 1 ? 2 : 0);
-                u32 maxSV = kind == 0 ? ZSA_MaxLL : (kind == 1 ? ZSA_MaxOff : ZSA_MaxML), tableLog = 0;
+            SD->err = err ? ZSA_dictionary_corrupted : 0;
+            SD->u[ZU_tmp] = p;
+        }
+        wv_sync();
+        for (int k = 0; k < 3; k++) {   // OF, ML, LL (:4848-4888)
+            if (SD->err) break;
+            int const kind = k == 0 ? 1 : (k == 1 ? 2 : 0);
+            ZsaFseCT* const ct = kind == 0 ? &SE->ll : (kind == 1 ? &SE->of : &SE->ml);
+            if (lane == 0) {
+                u32 err = 0, maxSV = kind == 0 ? ZSA_MaxLL : (kind == 1 ? ZSA_MaxOff : ZSA_MaxML), tableLog = 0;
                 u32 const maxLog = kind == 1 ? ZSA_OffFSELog : 9;
+                u32 const p = SD->u[ZU_tmp];
                 u32 const h = zsa_readNCount(SE->norm, &maxSV, &tableLog, dict + p, dictSize - p, &err);
-                if (err) break;
-                if (tableLog > maxLog) { err = ZSA_dictionary_corrupted; break; }
-                ZsaFseCT* const ct = kind == 0 ? &SE->ll : (kind == 1 ? &SE->of : &SE->ml);
-                // the offset table is built over all MaxOff+1 symbols (:4852-4857); readNCount zero-filled the tail
-                zsa_fse_buildCTable(SE, ct->nextState, ct->dfs, ct->dnb, SE->norm, kind == 1 ? ZSA_MaxOff : maxSV, tableLog);
-                ct->tableLog = tableLog;
-                if (kind == 2) out->mlRepeat = zsa_dictNCountRepeat(SE->norm, maxSV, ZSA_MaxML);
-                else if (kind == 0) out->llRepeat = zsa_dictNCountRepeat(SE->norm, maxSV, ZSA_MaxLL);
-                else { ofMaxSV = maxSV; for (u32 s = 0; s <= ZSA_MaxOff; s++) SD->norm[s] = SE->norm[s]; }   // decided below (:4896-4903)
-                p += h;
+                if (!err && tableLog > maxLog) err = ZSA_dictionary_corrupted;
+                if (err) SD->err = ZSA_dictionary_corrupted;
+                else {
+                    ct->tableLog = tableLog;
+                    if (kind == 2) out->mlRepeat = zsa_dictNCountRepeat(SE->norm, maxSV, ZSA_MaxML);
+                    else if (kind == 0) out->llRepeat = zsa_dictNCountRepeat(SE->norm, maxSV, ZSA_MaxLL);
+                    else { SD->u[ZU_seqOff] = maxSV; for (u32 s = 0; s <= ZSA_MaxOff; s++) SD->norm[s] = SE->norm[s]; }   // decided below (:4896-4903)
+                    SD->u[ZU_tmp] = p + h;
+                    // the offset table is built over all MaxOff+1 symbols (:4852-4857); readNCount zero-filled the tail
+                    SE->u[EU_s0] = kind == 1 ? ZSA_MaxOff : maxSV;
+                }
             }
-            if (!err && p + 12 > dictSize) err = ZSA_dictionary_corrupted;
+            wv_sync();
+            if (SD->err) break;
+            zsa_fse_buildCTable_wave(SE, ct->nextState, ct->dfs, ct->dnb, SE->norm, SE->u[EU_s0], ct->tableLog, lane);
+            wv_sync();
+        }
+        if (lane == 0 && !SD->err) {
+            u32 err = 0, p = SD->u[ZU_tmp];
+            u32 const ofMaxSV = SD->u[ZU_seqOff];
+            if (p + 12 > dictSize) err = ZSA_dictionary_corrupted;
             if (!err) {
                 out->rep[0] = zsa_ld32(dict + p); out->rep[1] = zsa_ld32(dict + p + 4); out->rep[2] = zsa_ld32(dict + p + 8);
                 p += 12;
                 u32 const dictContentSize = dictSize - p;
                 u32 offcodeMax = ZSA_MaxOff;
                 if (dictContentSize <= 0xFFFFFFFFu - 128 * 1024) offcodeMax = zsa_highbit32(dictContentSize + 128 * 1024);
-                ofRepeatMax = offcodeMax < ZSA_MaxOff ? offcodeMax : ZSA_MaxOff;
+                u32 const ofRepeatMax = offcodeMax < ZSA_MaxOff ? offcodeMax : ZSA_MaxOff;
                 out->ofRepeat = zsa_dictNCountRepeat(SD->norm, ofMaxSV, ofRepeatMax);
                 for (int u = 0; u < 3; u++) if (out->rep[u] == 0 || out->rep[u] > dictContentSize) err = ZSA_dictionary_corrupted;
                 out->dictID = zsa_ld32(dict + 4);

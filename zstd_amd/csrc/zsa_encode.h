@@ -159,7 +159,7 @@ struct ZsaWindow {
 
 #include "zsa_parse_dict.h"   // parse with an attached dictionary (zstd_fast.c:459-656), wave-level
 
-// ------------------------------------------------------------------ FSE (fse_compress.c), serial helpers
+// ------------------------------------------------------------------ FSE (fse_compress.c)
 ZSA_DEV u32 zsa_fse_minTableLog(u32 srcSize, u32 maxSV)
 {
     u32 const a = zsa_highbit32(srcSize) + 1, b = zsa_highbit32(maxSV) + 2;
@@ -176,180 +176,125 @@ ZSA_DEV u32 zsa_fse_optimalTableLog(u32 maxTableLog, u32 srcSize, u32 maxSV, u32
     if (tableLog > ZSA_FSE_MAX_TABLELOG) tableLog = ZSA_FSE_MAX_TABLELOG;
     return tableLog;
 }
-// fse_compress.c:379-463 FSE_normalizeM2; returns 0 ok, 1 error
-ZSA_DEV u32 zsa_fse_normalizeM2(s16* norm, u32 tableLog, const u32* count, u32 total, u32 maxSV, s16 lowProbCount)
+// inclusive prefix sum of 64-bit values over the 64 lanes
+ZSA_DEV u64 zsa_scan_incl64(u64 v, int lane)
 {
-    const s16 NOT_YET = -2;
-    u32 s, distributed = 0, toDistribute;
-    u32 const lowThreshold = total >> tableLog;
-    u32 lowOne = (u32)(((u64)total * 3) >> (tableLog + 1));
-    for (s = 0; s <= maxSV; s++) {
-        if (count[s] == 0) { norm[s] = 0; continue; }
-        if (count[s] <= lowThreshold) { norm[s] = lowProbCount; distributed++; total -= count[s]; continue; }
-        if (count[s] <= lowOne) { norm[s] = 1; distributed++; total -= count[s]; continue; }
-        norm[s] = NOT_YET;
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 const lo = wv_shfl_up((u32)v, d), hi = wv_shfl_up((u32)(v >> 32), d);
+        if (lane >= d) v += ((u64)hi << 32) | lo;
     }
-    toDistribute = (1u << tableLog) - distributed;
-    if (toDistribute == 0) return 0;
-    if ((total / toDistribute) > lowOne) {
-        lowOne = (u32)(((u64)total * 3) / (toDistribute * 2));
-        for (s = 0; s <= maxSV; s++)
-            if (norm[s] == NOT_YET && count[s] <= lowOne) { norm[s] = 1; distributed++; total -= count[s]; }
-        toDistribute = (1u << tableLog) - distributed;
-    }
-    if (distributed == maxSV + 1) {
-        u32 maxV = 0, maxC = 0;
-        for (s = 0; s <= maxSV; s++) if (count[s] > maxC) { maxV = s; maxC = count[s]; }
-        norm[maxV] += (s16)toDistribute;
-        return 0;
-    }
-    if (total == 0) {
-        for (s = 0; toDistribute > 0; s = (s + 1) % (maxSV + 1))
-            if (norm[s] > 0) { toDistribute--; norm[s]++; }
-        return 0;
-    }
-    {   u64 const vStepLog = 62 - tableLog;
-        u64 const mid = ((u64)1 << (vStepLog - 1)) - 1;
-        u64 const rStep = ((((u64)1 << vStepLog) * toDistribute) + mid) / total;
-        u64 tmpTotal = mid;
-        for (s = 0; s <= maxSV; s++) {
-            if (norm[s] == NOT_YET) {
-                u64 const end = tmpTotal + ((u64)count[s] * rStep);
-                u32 const sStart = (u32)(tmpTotal >> vStepLog), sEnd = (u32)(end >> vStepLog);
-                u32 const weight = sEnd - sStart;
-                if (weight < 1) return 1;
-                norm[s] = (s16)weight;
-                tmpTotal = end;
-            }
-        }
-    }
-    return 0;
+    return v;
 }
-// fse_compress.c:465-525 FSE_normalizeCount; returns 0 ok (norm filled; or rle special case flagged by *rle), 1 error
-ZSA_DEV u32 zsa_fse_normalizeCount(s16* norm, u32 tableLog, const u32* count, u32 total, u32 maxSV, u32 useLowProb)
+// The second-chance distribution of FSE_normalizeCount (fse_compress.c:379-463: reached when the proportional shares overshoot
+// the table by more than half of the largest share), by the whole wave, lane s <-> symbol s.  Symbols whose count is small
+// settle for one cell (or the low-probability mark); what the others get is a running total in symbol order -- a 64-bit
+// wave prefix sum -- cut at multiples of 2^(62 - tableLog).  Two corner cases end early: every symbol settled (the most
+// frequent one takes the cells left over) and nothing left to share out (the cells go round robin to the symbols that own
+// cells, in symbol order: a quotient for all and one more for the first few).  count, norm: LDS.  Returns 0 ok, 1 error (uniform).
+ZSA_DEV u32 zsa_fse_secondChance_wave(s16* norm, u32 tableLog, const u32* count, u32 total, u32 maxSV, int lowProbCount, int lane)
 {
-    const u32 rtb[8] = { 0, 473195, 504333, 520860, 550000, 700000, 750000, 830000 };
-    if (tableLog < ZSA_FSE_MIN_TABLELOG || tableLog > ZSA_FSE_MAX_TABLELOG) return 1;
-    if (tableLog < zsa_fse_minTableLog(total, maxSV)) return 1;
-    s16 const lowProbCount = useLowProb ? -1 : 1;
-    u64 const scale = 62 - tableLog;
-    u64 const step = ((u64)1 << 62) / total;
-    u64 const vStep = (u64)1 << (scale - 20);
-    int stillToDistribute = 1 << tableLog;
-    u32 largest = 0;
-    s16 largestP = 0;
-    u32 const lowThreshold = total >> tableLog;
-    for (u32 s = 0; s <= maxSV; s++) {
-        if (count[s] == total) return 0;
-        if (count[s] == 0) { norm[s] = 0; continue; }
-        if (count[s] <= lowThreshold) { norm[s] = lowProbCount; stillToDistribute--; }
-        else {
-            s16 proba = (s16)(((u64)count[s] * step) >> scale);
-            if (proba < 8) {
-                u64 const restToBeat = vStep * rtb[proba];
-                proba += ((u64)count[s] * step) - ((u64)proba << scale) > restToBeat;
-            }
-            if (proba > largestP) { largestP = proba; largest = s; }
-            norm[s] = proba;
-            stillToDistribute -= proba;
+    bool const mine = (u32)lane <= maxSV;
+    u32 const c = mine ? count[lane] : 0u;
+    u32 const tableSize = 1u << tableLog;
+    u32 const rare = total >> tableLog;                                   // at or below: the low-probability mark
+    u32 single = (u32)(((u64)total * 3) >> (tableLog + 1));              // at or below: one cell
+    int share = 0;
+    bool open = false;                                                    // still waiting for a proportional share
+    if (c != 0) { if (c <= rare) share = lowProbCount; else if (c <= single) share = 1; else { share = -2; open = true; } }
+    bool const settled = c != 0 && !open;
+    u32 given = (u32)__builtin_popcountll(wv_ballot(settled));
+    u32 rest = total - wv_reduce_add(settled ? c : 0u);                   // occurrences of the open symbols
+    u32 cellsLeft = tableSize - given;
+    u32 bad = 0;
+    ZSA_STAT(7);
+    if (cellsLeft != 0) {
+        if ((rest / cellsLeft) > single) {                                // the open symbols are few and heavy: settle the lighter ones too
+            single = (u32)(((u64)rest * 3) / (cellsLeft * 2));
+            bool const now = open && c <= single;
+            if (now) { share = 1; open = false; }
+            given += (u32)__builtin_popcountll(wv_ballot(now));
+            rest -= wv_reduce_add(now ? c : 0u);
+            cellsLeft = tableSize - given;
+        }
+        if (given == maxSV + 1) {                                         // every symbol settled: the first of the most frequent takes the rest
+            u32 const top = wv_reduce_max(c);
+            if ((u32)lane == (u32)__builtin_ctzll(wv_ballot(mine && c == top))) share += (int)cellsLeft;
+        } else if (rest == 0) {                                           // round robin over the symbols that own cells
+            bool const owner = mine && share > 0;
+            u64 const om = wv_ballot(owner);
+            u32 const owners = (u32)__builtin_popcountll(om), before = (u32)__builtin_popcountll(om & ((1ull << lane) - 1ull));
+            if (owner && cellsLeft) share += (int)(cellsLeft / owners + (before < cellsLeft % owners ? 1u : 0u));
+        } else {
+            u32 const unitLog = 62 - tableLog;
+            u64 const half = ((u64)1 << (unitLog - 1)) - 1;
+            u64 const perOccurrence = ((((u64)1 << unitLog) * cellsLeft) + half) / rest;
+            u64 const mass = open ? (u64)c * perOccurrence : 0;
+            u64 const upTo = half + zsa_scan_incl64(mass, lane), from = upTo - mass;
+            u32 const cells = (u32)(upTo >> unitLog) - (u32)(from >> unitLog);
+            bad = wv_ballot(open && cells < 1) ? 1u : 0u;
+            if (open) share = (int)cells;
         }
     }
-    if (-stillToDistribute >= (norm[largest] >> 1)) return zsa_fse_normalizeM2(norm, tableLog, count, total, maxSV, lowProbCount);
-    norm[largest] += (s16)stillToDistribute;
-    return 0;
+    if (mine) norm[lane] = (s16)share;
+    wv_lds_fence();
+    return bad;
 }
-// fse_compress.c:234-340 FSE_writeNCount (output buffer is always large enough here); returns size, 0 on error
-ZSA_DEV u32 zsa_fse_writeNCount(u8* dst, const s16* norm, u32 maxSV, u32 tableLog)
+// FSE_writeNCount (fse_compress.c:234-340) by the whole wave, lane s <-> symbol s.  The description is a concatenation of bit
+// fields, one per symbol, whose width and value depend on the cells still unassigned before the symbol -- a prefix sum of the
+// cell counts; a symbol without cells that follows another one emits nothing: the first of such a run carries the run's length
+// behind its own field (16 one-bits per 24, two one-bits per 3, two bits for the rest).  Every lane makes its field (at most 58
+// bits), a prefix sum of the widths places it, the fields are or-ed into 128 bytes of LDS and copied out.  norm: LDS; dst:
+// anywhere.  Returns the size in bytes, 0 on error (uniform).  Uses S->cumul.
+ZSA_DEV u32 zsa_fse_writeNCount_wave(ZsaEncShared* S, u8* dst, const s16* norm, u32 maxSV, u32 tableLog, int lane)
 {
-    u8* out = dst;
-    int nbBits, remaining, threshold, bitCount = 0, previousIs0 = 0;
-    int const tableSize = 1 << tableLog;
-    u32 bitStream = 0, symbol = 0;
-    u32 const alphabetSize = maxSV + 1;
-    bitStream += (tableLog - ZSA_FSE_MIN_TABLELOG) << bitCount;
-    bitCount += 4;
-    remaining = tableSize + 1;
-    threshold = tableSize;
-    nbBits = (int)tableLog + 1;
-    while ((symbol < alphabetSize) && (remaining > 1)) {
-        if (previousIs0) {
-            u32 start = symbol;
-            while ((symbol < alphabetSize) && !norm[symbol]) symbol++;
-            if (symbol == alphabetSize) break;
-            while (symbol >= start + 24) {
-                start += 24;
-                bitStream += 0xFFFFU << bitCount;
-                out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += 2;
-                bitStream >>= 16;
-            }
-            while (symbol >= start + 3) { start += 3; bitStream += 3u << bitCount; bitCount += 2; }
-            bitStream += (symbol - start) << bitCount;
-            bitCount += 2;
-            if (bitCount > 16) { out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += 2; bitStream >>= 16; bitCount -= 16; }
-        }
-        {   int count = norm[symbol++];
-            int const max = (2 * threshold - 1) - remaining;
-            remaining -= count < 0 ? -count : count;
-            count++;
-            if (count >= threshold) count += max;
-            bitStream += (u32)count << bitCount;
-            bitCount += nbBits;
-            bitCount -= (count < max);
-            previousIs0 = (count == 1);
-            if (remaining < 1) return 0;
-            while (remaining < threshold) { nbBits--; threshold >>= 1; }
-        }
-        if (bitCount > 16) { out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += 2; bitStream >>= 16; bitCount -= 16; }
-    }
-    if (remaining != 1) return 0;
-    out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8);
-    out += (bitCount + 7) / 8;
-    return (u32)(out - dst);
-}
-// fse_compress.c:69-215 FSE_buildCTable_wksp (generic spreading)
-ZSA_DEV void zsa_fse_buildCTable(ZsaEncShared* S, u16* nextState, s32* dfs, u32* dnb, const s16* norm, u32 maxSV, u32 tableLog)
-{
-    u32 const tableSize = 1u << tableLog, tableMask = tableSize - 1, step = ZSA_FSE_TABLESTEP(tableSize);
-    u32 const maxSV1 = maxSV + 1;
-    u16* const cumul = S->cumul;
-    u8* const tableSymbol = S->tableSymbol;
-    u32 highThreshold = tableSize - 1;
-    cumul[0] = 0;
-    for (u32 u = 1; u <= maxSV1; u++) {
-        if (norm[u - 1] == -1) { cumul[u] = cumul[u - 1] + 1; tableSymbol[highThreshold--] = (u8)(u - 1); }
-        else cumul[u] = cumul[u - 1] + (u16)norm[u - 1];
-    }
-    cumul[maxSV1] = (u16)(tableSize + 1);
-    {   u32 position = 0;
-        for (u32 s = 0; s < maxSV1; s++) {
-            int const freq = norm[s];
-            for (int n = 0; n < freq; n++) {
-                tableSymbol[position] = (u8)s;
-                position = (position + step) & tableMask;
-                while (position > highThreshold) position = (position + step) & tableMask;
-            }
+    u32 const tableSize = 1u << tableLog;
+    bool const inAlpha = (u32)lane <= maxSV;
+    int const n = inAlpha ? (int)norm[lane] : 0;
+    u32 const cells = (u32)(n < 0 ? -n : n);
+    u32 const upTo = wv_scan_incl(cells), before = upTo - cells;
+    if (wv_readlane(upTo, 63) != tableSize) return 0;                     // (:299, :304: the cells must add up to the table)
+    u64 const empty = wv_ballot(inAlpha && n == 0);
+    bool const inRun = n == 0 && lane > 0 && ((empty >> (lane - 1)) & 1ull) != 0;
+    u64 field = 0; u32 width = 0;
+    if (inAlpha && before < tableSize && !inRun) {                        // (:274: symbols are described while cells remain)
+        u32 const remaining = tableSize + 1 - before, top = zsa_highbit32(remaining), threshold = 1u << top;
+        u32 const spare = 2 * threshold - 1 - remaining;                  // values below it take one bit less
+        u32 v = (u32)(n + 1);
+        if (v >= threshold) v += spare;
+        width = top + 1 - (v < spare ? 1u : 0u);
+        field = v;
+        if (n == 0) {
+            u32 const run = (u32)__builtin_ctzll(~(empty >> (lane + 1)));   // empty symbols right behind this one
+            u32 const by24 = run / 24, r24 = run - 24 * by24, by3 = r24 / 3, r3 = r24 - 3 * by3;
+            field |= (((u64)1 << (16 * by24)) - 1) << width; width += 16 * by24;
+            field |= (((u64)1 << (2 * by3)) - 1) << width;   width += 2 * by3;
+            field |= (u64)r3 << width;                       width += 2;
         }
     }
-    for (u32 u = 0; u < tableSize; u++) { u32 const sy = tableSymbol[u]; nextState[cumul[sy]++] = (u16)(tableSize + u); }
-    {   u32 total = 0;
-        for (u32 s = 0; s <= maxSV; s++) {
-            int const nc = norm[s];
-            if (nc == 0) { dnb[s] = ((tableLog + 1) << 16) - (1u << tableLog); dfs[s] = 0; }
-            else if (nc == -1 || nc == 1) { dnb[s] = (tableLog << 16) - (1u << tableLog); dfs[s] = (s32)(total - 1); total++; }
-            else {
-                u32 const maxBitsOut = tableLog - zsa_highbit32((u32)nc - 1);
-                u32 const minStatePlus = (u32)nc << maxBitsOut;
-                dnb[s] = (maxBitsOut << 16) - minStatePlus;
-                dfs[s] = (s32)(total - (u32)nc);
-                total += (u32)nc;
-            }
-        }
+    u32 const endBit = wv_scan_incl(width), at = 4 + endBit - width;
+    u32 const totalBits = 4 + wv_readlane(endBit, 63);
+    u32* const buf = (u32*)S->cumul;
+    wv_lds_fence();
+    if (lane < 32) buf[lane] = lane == 0 ? tableLog - ZSA_FSE_MIN_TABLELOG : 0u;
+    wv_lds_fence();
+    if (width) {
+        u32 const w = at >> 5, sh = at & 31u;
+        u64 const lo = field << sh;
+        u32 const hi = sh ? (u32)(field >> (64 - sh)) : 0u;
+        (void)wv_atomic_or_lds(&buf[w], (u32)lo);
+        if ((u32)(lo >> 32)) (void)wv_atomic_or_lds(&buf[w + 1], (u32)(lo >> 32));
+        if (hi) (void)wv_atomic_or_lds(&buf[w + 2], hi);
     }
+    wv_lds_fence();
+    u32 const size = (totalBits + 7) >> 3;
+    for (u32 i = (u32)lane; i < size; i += ZSA_WAVE) dst[i] = ((const u8*)buf)[i];
+    wv_lds_fence();
+    return size;
 }
 // The same normalisation by the whole wave, lane s <-> symbol s (sequence codes: at most 53 symbols).  count, norm: LDS.
 // Every symbol's share is independent of the others (fse_compress.c:487-508); what couples them -- the cells left over, the
 // first symbol with the largest share, which absorbs them -- is a wave sum, a wave maximum and a ballot.  The rare
-// second-chance distribution (FSE_normalizeM2) stays a serial routine on lane 0.  Returns 0 ok, 1 error; wave-uniform.
+// second-chance distribution is zsa_fse_secondChance_wave above.  Returns 0 ok, 1 error; wave-uniform.
 ZSA_DEV u32 zsa_fse_normalizeCount_wave(s16* norm, u32 tableLog, const u32* count, u32 total, u32 maxSV, u32 useLowProb, int lane)
 {
     if (tableLog < ZSA_FSE_MIN_TABLELOG || tableLog > ZSA_FSE_MAX_TABLELOG) return 1;
@@ -380,12 +325,7 @@ ZSA_DEV u32 zsa_fse_normalizeCount_wave(s16* norm, u32 tableLog, const u32* coun
     wv_lds_fence();
     int const atLargest = norm[largest];
     wv_lds_fence();
-    if (-still >= (atLargest >> 1)) {
-        u32 r = 0;
-        if (lane == 0) r = zsa_fse_normalizeM2(norm, tableLog, count, total, maxSV, (s16)lowProbCount);
-        wv_lds_fence();
-        return wv_shfl(r, 0);
-    }
+    if (-still >= (atLargest >> 1)) return zsa_fse_secondChance_wave(norm, tableLog, count, total, maxSV, lowProbCount, lane);
     if ((u32)lane == largest) norm[largest] = (s16)(atLargest + still);
     wv_lds_fence();
     return 0;
@@ -432,47 +372,42 @@ ZSA_DEV void zsa_fse_encodeSymbol(ZsaBitW& w, ZsaFseCState& st, u32 symbol)
 
 // ------------------------------------------------------------------ Huffman table construction (huf_compress.c), serial
 ZSA_DEV u32 zsa_huf_bucket(u32 count) { return (count < 166) ? count : zsa_highbit32(count) + 158; }
-ZSA_DEV void zsa_huf_insertionSort(ZsaHufNode* a, int low, int high)
-{   // huf_compress.c:531-544
-    int const size = high - low + 1;
-    a += low;
-    for (int i = 1; i < size; ++i) {
-        ZsaHufNode const key = a[i];
-        int j = i - 1;
-        while (j >= 0 && a[j].count < key.count) { a[j + 1] = a[j]; j--; }
-        a[j + 1] = key;
-    }
-}
-ZSA_DEV int zsa_huf_partition(ZsaHufNode* a, int low, int high)
-{   // huf_compress.c:547-562
-    u32 const pivot = a[high].count;
-    int i = low - 1;
-    for (int j = low; j < high; j++) {
-        if (a[j].count > pivot) { i++; ZsaHufNode const t = a[i]; a[i] = a[j]; a[j] = t; }
-    }
-    { ZsaHufNode const t = a[i + 1]; a[i + 1] = a[high]; a[high] = t; }
-    return i + 1;
-}
-ZSA_DEV void zsa_huf_quickSort(ZsaHufNode* a, int low0, int high0)
-{   // huf_compress.c:567-583 HUF_simpleQuickSort.  Device code has no recursion: the call stack is explicit.
-    // A frame is one activation; `fresh` marks an activation that has not yet taken its "< 8 -> insertion sort"
-    // test.  As in the reference, an activation recurses into the SMALLER side and keeps partitioning the larger
-    // one itself (without re-testing the threshold), so the depth is bounded by log2(256).
-    int lo[12], hi[12], fresh[12], sp = 1;
-    lo[0] = low0; hi[0] = high0; fresh[0] = 1;
-    while (sp > 0) {
-        int const f = sp - 1;
-        if (fresh[f]) {
-            fresh[f] = 0;
-            if (hi[f] - lo[f] < 8) { zsa_huf_insertionSort(a, lo[f], hi[f]); sp--; continue; }
+// Orders ranks [first, last] of one large-count bucket by descending count the way the reference's sort does
+// (huf_compress.c:531-583).  That sort is not stable, and which of two equally frequent symbols ends up first decides which
+// gets the shorter code, so the result has to be reproduced element move for element move: spans of fewer than 8 elements are
+// built up by insertion; longer ones are split around the count of their last element (larger counts swapped to the front in
+// the order they are met), the shorter part becomes a span of its own and is finished first, the longer part is split on
+// without being tested for "short" again.  Device code has no recursion: the spans wait on a small stack (depth <= log2(256)).
+ZSA_DEV void zsa_huf_orderBucket(ZsaHufNode* a, int first, int last)
+{
+    int lo[12], hi[12]; bool untested[12];
+    int depth = 1;
+    lo[0] = first; hi[0] = last; untested[0] = true;
+    while (depth > 0) {
+        int const t = depth - 1;
+        if (untested[t]) {
+            untested[t] = false;
+            if (hi[t] - lo[t] < 8) {
+                for (int i = lo[t] + 1; i <= hi[t]; i++) {
+                    ZsaHufNode const x = a[i];
+                    int j = i;
+                    while (j > lo[t] && a[j - 1].count < x.count) { a[j] = a[j - 1]; j--; }
+                    a[j] = x;
+                }
+                depth--;
+                continue;
+            }
         }
-        if (lo[f] < hi[f]) {
-            int const idx = zsa_huf_partition(a, lo[f], hi[f]);
-            int cl, ch;
-            if (idx - lo[f] < hi[f] - idx) { cl = lo[f]; ch = idx - 1; lo[f] = idx + 1; }
-            else { cl = idx + 1; ch = hi[f]; hi[f] = idx - 1; }
-            lo[sp] = cl; hi[sp] = ch; fresh[sp] = 1; sp++;
-        } else sp--;
+        if (lo[t] >= hi[t]) { depth--; continue; }
+        u32 const pivot = a[hi[t]].count;
+        int w = lo[t];                                           // where the next larger count goes
+        for (int r = lo[t]; r < hi[t]; r++)
+            if (a[r].count > pivot) { ZsaHufNode const x = a[w]; a[w] = a[r]; a[r] = x; w++; }
+        { ZsaHufNode const x = a[w]; a[w] = a[hi[t]]; a[hi[t]] = x; }
+        if (w - lo[t] < hi[t] - w) { lo[depth] = lo[t]; hi[depth] = w - 1; lo[t] = w + 1; }
+        else { lo[depth] = w + 1; hi[depth] = hi[t]; hi[t] = w - 1; }
+        untested[depth] = true;
+        depth++;
     }
 }
 // HUF_sort (huf_compress.c:596-641) by the whole wave.  The reference drops the symbols into buckets (counts below 166: one
@@ -509,7 +444,7 @@ ZSA_DEV u32 zsa_huf_sort_wave(ZsaHufNode* node, const u32* count, u32 maxSV, int
     for (u32 b = 190; b >= 165; b--) {
         u32 size = 0;
         for (u32 k = 0; k < 4; k++) size += (u32)__builtin_popcountll(wv_ballot((key[k] >> 8) == b + 1u));
-        if (size > 1 && lane == 0) zsa_huf_quickSort(node + start, 0, (int)size - 1);
+        if (size > 1 && lane == 0) zsa_huf_orderBucket(node + start, 0, (int)size - 1);
         start += size;
     }
     wv_sync();
@@ -543,62 +478,72 @@ ZSA_DEV void zsa_huf_buildTree_wave(ZsaHufNode* node, u32 nonNullRank, int lane)
     for (int n = lane; n <= (int)nonNullRank; n += ZSA_WAVE) node[n].nbBits = node[node[n].parent].nbBits + 1;
     wv_sync();
 }
-// huf_compress.c:352-474 HUF_setMaxHeight
-ZSA_DEV u32 zsa_huf_setMaxHeight(ZsaHufNode* node, u32 lastNonNull, u32 targetNbBits)
+// Depth limit of the Huffman tree (huf_compress.c:352-474), nodes in rank order (descending count, depths non-decreasing).
+// By all lanes: every leaf deeper than the limit is cut to it, which over-subscribes the code space by a debt counted in
+// units of the deepest code -- a wave sum; the last rank of every depth below the limit -- where a leaf can be pushed one
+// level down to repay 2^(steps below the limit - 1) units -- is a ballot per depth.  The repayment itself is a short chain of
+// decisions that each read what the previous one changed (a handful of steps): wave-uniform scalar work, stores by lane 0.
+// lastAt: LDS, ZSA_HUF_TABLELOG_MAX + 2 entries.  Returns the depth of the deepest leaf afterwards (uniform).
+ZSA_DEV u32 zsa_huf_limitDepth_wave(ZsaHufNode* node, u16* lastAt, u32 lastRank, u32 limit, int lane)
 {
-    u32 const largestBits = node[lastNonNull].nbBits;
-    if (largestBits <= targetNbBits) return largestBits;
-    int totalCost = 0;
-    u32 const baseCost = 1u << (largestBits - targetNbBits);
-    int n = (int)lastNonNull;
-    while (node[n].nbBits > targetNbBits) {
-        totalCost += (int)(baseCost - (1u << (largestBits - node[n].nbBits)));
-        node[n].nbBits = (u8)targetNbBits;
-        n--;
+    u32 const deepest = node[lastRank].nbBits;
+    if (deepest <= limit) return deepest;
+    u32 const NONE = 0xFFFFu;
+    // cut, and count the debt
+    u32 depth[4], owed = 0;
+    wv_lds_fence();
+    for (u32 k = 0; k < 4; k++) {
+        u32 const r = (u32)lane + 64u * k;
+        depth[k] = r <= lastRank ? node[r].nbBits : 0xFFu;
+        if (depth[k] != 0xFFu && depth[k] > limit) { owed += (1u << (deepest - limit)) - (1u << (deepest - depth[k])); node[r].nbBits = (u8)limit; depth[k] = limit; }
     }
-    while (node[n].nbBits == targetNbBits) --n;
-    totalCost >>= (largestBits - targetNbBits);
-    u32 const noSymbol = 0xF0F0F0F0;
-    u32 rankLast[ZSA_HUF_TABLELOG_MAX + 2];
-    for (u32 i = 0; i < ZSA_HUF_TABLELOG_MAX + 2; i++) rankLast[i] = noSymbol;
-    {   u32 currentNbBits = targetNbBits;
-        for (int pos = n; pos >= 0; pos--) {
-            if (node[pos].nbBits >= currentNbBits) continue;
-            currentNbBits = node[pos].nbBits;
-            rankLast[targetNbBits - currentNbBits] = (u32)pos;
+    int debt = (int)(wv_reduce_add(owed) >> (deepest - limit));
+    // the last rank of every depth below the limit, and the last rank above which everything sits at the limit
+    u32 below = 0;                                               // highest rank with a depth below the limit
+    for (u32 d = 1; d <= ZSA_HUF_TABLELOG_MAX + 1; d++) {
+        u32 at = NONE;
+        if (d < limit) for (int k = 3; k >= 0; k--) {
+            u64 const m = wv_ballot(depth[k] == limit - d);
+            if (m) { at = 64u * (u32)k + 63u - (u32)__builtin_clzll(m); break; }
         }
+        if (at != NONE && at > below) below = at;
+        if ((u32)lane == d) lastAt[d] = (u16)at;
     }
-    while (totalCost > 0) {
-        u32 nBitsToDecrease = zsa_highbit32((u32)totalCost) + 1;
-        for (; nBitsToDecrease > 1; nBitsToDecrease--) {
-            u32 const highPos = rankLast[nBitsToDecrease], lowPos = rankLast[nBitsToDecrease - 1];
-            if (highPos == noSymbol) continue;
-            if (lowPos == noSymbol) break;
-            if (node[highPos].count <= 2 * node[lowPos].count) break;
+    if (lane == 0) lastAt[0] = (u16)NONE;
+    wv_lds_fence();
+    // repay: lengthen the cheapest suitable leaf -- starting from the largest step that does not overshoot, a smaller step is
+    // preferred while the leaf it would push down is less than twice as frequent as the one of the larger step
+    while (debt > 0) {
+        u32 d = zsa_highbit32((u32)debt) + 1;
+        for (; d > 1; d--) {
+            u32 const big = lastAt[d], small = lastAt[d - 1];
+            if (big == NONE) continue;
+            if (small == NONE) break;
+            if (node[big].count <= 2 * node[small].count) break;
         }
-        while ((nBitsToDecrease <= ZSA_HUF_TABLELOG_MAX) && (rankLast[nBitsToDecrease] == noSymbol)) nBitsToDecrease++;
-        totalCost -= 1 << (nBitsToDecrease - 1);
-        node[rankLast[nBitsToDecrease]].nbBits++;
-        if (rankLast[nBitsToDecrease - 1] == noSymbol) rankLast[nBitsToDecrease - 1] = rankLast[nBitsToDecrease];
-        if (rankLast[nBitsToDecrease] == 0) rankLast[nBitsToDecrease] = noSymbol;
-        else {
-            rankLast[nBitsToDecrease]--;
-            if (node[rankLast[nBitsToDecrease]].nbBits != targetNbBits - nBitsToDecrease) rankLast[nBitsToDecrease] = noSymbol;
+        while (d <= ZSA_HUF_TABLELOG_MAX && lastAt[d] == NONE) d++;
+        u32 const r = lastAt[d];
+        debt -= 1 << (d - 1);
+        u32 const under = r != 0 ? (u32)node[r - 1].nbBits : 0xFFu;   // (read before the store below: ranks differ)
+        wv_lds_fence();
+        if (lane == 0) {
+            node[r].nbBits++;                                    // rank r now sits d - 1 steps below the limit -- and is the last one there
+            if (lastAt[d - 1] == NONE) lastAt[d - 1] = (u16)r;
+            lastAt[d] = (u16)((r != 0 && under == limit - d) ? r - 1 : NONE);
         }
+        wv_lds_fence();
     }
-    while (totalCost < 0) {
-        if (rankLast[1] == noSymbol) {
-            while (node[n].nbBits == targetNbBits) n--;
-            node[n + 1].nbBits--;
-            rankLast[1] = (u32)(n + 1);
-            totalCost++;
-            continue;
-        }
-        node[rankLast[1] + 1].nbBits--;
-        rankLast[1]++;
-        totalCost++;
+    // overpaid (the steps are powers of two): take leaves at the limit one level up again, highest ranks first
+    while (debt < 0) {
+        u32 r;
+        if (lastAt[1] == NONE) { while (node[below].nbBits == limit) below--; r = below + 1; }
+        else r = (u32)lastAt[1] + 1;
+        wv_lds_fence();
+        if (lane == 0) { node[r].nbBits--; lastAt[1] = (u16)r; }
+        wv_lds_fence();
+        debt++;
     }
-    return targetNbBits;
+    return limit;
 }
 // HUF_buildCTable_wksp (huf_compress.c:730-766 + :706-728) by all lanes; returns maxNbBits (0 on error), uniform.
 // Code values: symbols of one length take consecutive values in symbol order -- the rank of a symbol among the symbols of its
@@ -610,9 +555,8 @@ ZSA_DEV u32 zsa_huf_buildCTable_wave(ZsaEncShared* S, ZsaHufCT* ct, const u32* c
     wv_sync();
     u32 const nonNullRank = zsa_huf_sort_wave(node, count, maxSV, lane);
     zsa_huf_buildTree_wave(node, nonNullRank, lane);
-    if (lane == 0) S->u[EU_s0] = zsa_huf_setMaxHeight(node, nonNullRank, maxNbBits);
+    maxNbBits = zsa_huf_limitDepth_wave(node, S->rpBase, nonNullRank, maxNbBits, lane);
     wv_sync();
-    maxNbBits = S->u[EU_s0];
     if (maxNbBits > ZSA_HUF_TABLELOG_MAX) return 0;
     for (u32 i = (u32)lane; i < 256; i += ZSA_WAVE) { ct->nbBits[i] = 0; ct->val[i] = 0; }
     wv_sync();
@@ -672,9 +616,7 @@ ZSA_DEV u32 zsa_huf_compressWeights_wave(ZsaEncShared* S, u8* dst, const u8* wei
     wv_lds_fence();
     if (zsa_fse_normalizeCount_wave(S->norm, tableLog, wcount, wtSize, maxSV, 0, lane)) return 0xFFFFFFFFu;
     wv_lds_fence();
-    u32 h = 0;
-    if (lane == 0) h = zsa_fse_writeNCount(dst, S->norm, maxSV, tableLog);
-    h = wv_readlane(h, 0);
+    u32 const h = zsa_fse_writeNCount_wave(S, dst, S->norm, maxSV, tableLog, lane);
     if (h == 0) return 0xFFFFFFFFu;
     zsa_fse_buildCTable_wave(S, S->wtNext, S->wtDfs, S->wtDnb, S->norm, maxSV, tableLog, lane);
     wv_sync();
@@ -729,15 +671,6 @@ ZSA_DEV u32 zsa_huf_estimate(const ZsaHufCT* ct, const u32* count, u32 maxSV, in
     for (u32 s = (u32)lane; s <= maxSV; s += ZSA_WAVE) nbBits += (u32)ct->nbBits[s] * count[s];
     return wv_reduce_add(nbBits) >> 3;
 }
-// one Huffman stream, symbols last -> first, end mark (huf_compress.c:1023-1086, :941-950); run by one lane
-ZSA_DEV u32 zsa_huf_encode1X(u8* dst, const u8* src, u32 srcSize, const ZsaHufCT* ct)
-{
-    ZsaBitW w;
-    zsa_bw_init(w, dst);
-    for (u32 n = srcSize; n > 0; ) { u32 const s = src[--n]; zsa_bw_add(w, ct->val[s], ct->nbBits[s]); }
-    return zsa_bw_close(w);
-}
-
 // The same stream written by all lanes: 256 symbols per step (4 per lane, last symbol first), prefix sum of the code
 // lengths, LDS atomic-or packing, whole words flushed together.  Returns the stream size (uniform).
 ZSA_DEV u32 zsa_huf_encode_wave(ZsaEncShared* S, u8* dst, const u8* src, u32 srcSize, const ZsaHufCT* ct, int lane);
@@ -1064,8 +997,7 @@ ZSA_DEV u32 zsa_selectEncodingType(ZsaEncShared* S, u32* repeatMode, const u32* 
             u32 NCountCost = 0;
             if (zsa_fse_normalizeCount_wave(S->norm, tableLog, count, nbSeq, max, nbSeq >= 2048, lane)) NCountCost = ZSA_COST_ERROR >> 3;
             else {
-                if (lane == 0) NCountCost = zsa_fse_writeNCount(wksp, S->norm, max, tableLog);
-                NCountCost = wv_shfl(NCountCost, 0);
+                NCountCost = zsa_fse_writeNCount_wave(S, wksp, S->norm, max, tableLog, lane);
             }
             u32 norm = (256 * c) / nbSeq;
             if (c != 0 && norm == 0) norm = 1;
@@ -1118,9 +1050,7 @@ ZSA_DEV u32 zsa_buildSeqCTable(ZsaEncShared* S, u8* dst, ZsaFseCT* ct, int kind,
         if (cLast > 1) { if (lane == 0) count[lastCode] = cLast - 1; nbSeq_1--; }
         wv_lds_fence();
         if (zsa_fse_normalizeCount_wave(S->norm, tableLog, count, nbSeq_1, max, nbSeq_1 >= 2048, lane)) { *fail = 1; return 0; }
-        u32 NCountSize = 0;
-        if (lane == 0) NCountSize = zsa_fse_writeNCount(dst, S->norm, max, tableLog);
-        NCountSize = wv_shfl(NCountSize, 0);
+        u32 const NCountSize = zsa_fse_writeNCount_wave(S, dst, S->norm, max, tableLog, lane);
         if (NCountSize == 0) { *fail = 1; return 0; }
         zsa_fse_buildCTable_wave(S, ct->nextState, ct->dfs, ct->dnb, S->norm, max, tableLog, lane);
         if (lane == 0) { ct->tableLog = tableLog; ct->maxSV = max; }

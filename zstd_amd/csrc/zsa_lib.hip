@@ -5,6 +5,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <atomic>
+#include <chrono>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -173,10 +175,24 @@ __global__ void zsa_k_export_sizes(const u64* __restrict__ results, s32* __restr
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "libzstd_amd: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return ZSA_ERR(ZSA_GENERIC); } } while (0)
+// Engine-side failures -- no usable device, a HIP call that failed, device memory that could not be had, a batch used under
+// another device -- are not answers about the caller's data: libzstd on the CPU cannot produce them.  They are returned as
+// the nearest libzstd code and, in addition, flagged per calling thread, so that a binding can tell them from data errors
+// and answer with its CPU path (zsa_engine_failure, include/zstd_amd.h section 5; shim/zstd_amd_on.go).
+enum { ZSA_EF_NONE = 0, ZSA_EF_NO_DEVICE = 1, ZSA_EF_RUNTIME = 2, ZSA_EF_MEMORY = 3, ZSA_EF_DEVICE_MISMATCH = 4 };
+static thread_local int t_engineFailure = ZSA_EF_NONE;
+static size_t zsa_fail(int why, size_t code) { t_engineFailure = why; return code; }
+extern "C" int zsa_engine_failure(void) { return t_engineFailure; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "libzstd_amd: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); (void)hipGetLastError(); return zsa_fail(ZSA_EF_RUNTIME, ZSA_ERR(ZSA_GENERIC)); } } while (0)
 
 static const size_t kErrMemory = (size_t)ZSA_ERR(ZSA_memory_allocation);
 static const size_t kErrGeneric = (size_t)ZSA_ERR(ZSA_GENERIC);
+// test knob: ZSTD_AMD_FAIL=alloc makes every workspace / staging allocation of the data path fail (tests/abi_smoke.c)
+static bool zsa_forced_alloc_failure()
+{
+    static int const on = [] { const char* e = getenv("ZSTD_AMD_FAIL"); return (e && strcmp(e, "alloc") == 0) ? 1 : 0; }();
+    return on != 0;
+}
 
 struct zsa_batch_s {
     size_t maxFrames, nFrames;
@@ -284,6 +300,10 @@ extern "C" unsigned long long zsa_getFrameContentSize(const void* srcv, size_t s
     }
 }
 
+// address of the allocation-free entry point's workspace on device `dev` (section 4 of the header), resolved when a batch or a
+// decompression dictionary is created on the device, so that the entry point itself makes no runtime query
+static u8* zsa_na_address(int dev);
+
 // ---- dictionaries (device-resident digests)
 #include "zsa_dict.inc"
 
@@ -307,7 +327,7 @@ extern "C" void zsa_batch_free(zsa_batch* b)
 extern "C" zsa_batch* zsa_batch_create(size_t maxFrames)
 {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) { fprintf(stderr, "libzstd_amd: no usable HIP device\n"); return NULL; }
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); t_engineFailure = ZSA_EF_NO_DEVICE; fprintf(stderr, "libzstd_amd: no usable HIP device\n"); return NULL; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return NULL;
     zsa_batch* b = (zsa_batch*)calloc(1, sizeof(zsa_batch));
@@ -328,7 +348,8 @@ extern "C" zsa_batch* zsa_batch_create(size_t maxFrames)
            && hipMalloc((void**)&b->d_counter, 256) == hipSuccess
            && hipMalloc((void**)&b->d_prof, ZSA_NPROF * sizeof(u64)) == hipSuccess
            && hipMalloc((void**)&b->d_scratch, b->scratchBytes) == hipSuccess;
-    if (!ok) { fprintf(stderr, "libzstd_amd: device allocation failed (%zu frames)\n", maxFrames); zsa_batch_free(b); return NULL; }
+    if (!ok) { (void)hipGetLastError(); t_engineFailure = ZSA_EF_MEMORY; fprintf(stderr, "libzstd_amd: device allocation failed (%zu frames)\n", maxFrames); zsa_batch_free(b); return NULL; }
+    (void)zsa_na_address(dev);
     return b;
 }
 extern "C" size_t zsa_batch_set_frame(zsa_batch* b, size_t i, const void* d_src, size_t srcSize, void* d_dst, size_t dstCapacity)
@@ -384,11 +405,11 @@ static unsigned zsa_grid(const zsa_batch* b, size_t ldsPerWG)
 static size_t zsa_check_device(const zsa_batch* b, int dictDevice)
 {
     int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess) { fprintf(stderr, "libzstd_amd: no usable HIP device -- this library has no CPU path\n"); return kErrGeneric; }
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); fprintf(stderr, "libzstd_amd: no usable HIP device -- this library has no CPU path\n"); return zsa_fail(ZSA_EF_NO_DEVICE, kErrGeneric); }
     if (dev != b->device || (dictDevice >= 0 && dictDevice != b->device)) {
         fprintf(stderr, "libzstd_amd: device mismatch: current HIP device %d, batch created on %d%s -- refusing to launch\n",
                 dev, b->device, (dictDevice >= 0 && dictDevice != b->device) ? ", dictionary on another device" : "");
-        return (size_t)ZSA_ERR(ZSA_stage_wrong);
+        return zsa_fail(ZSA_EF_DEVICE_MISMATCH, (size_t)ZSA_ERR(ZSA_stage_wrong));
     }
     return 0;
 }
@@ -411,6 +432,7 @@ static void zsa_plan_compress(zsa_batch* b, int level, const zsa_CDict* cdict)
 }
 extern "C" size_t zsa_compress_enqueue(zsa_batch* b, int level, const zsa_CDict* cdict, void* stream)
 {
+    t_engineFailure = ZSA_EF_NONE;
     if (!b) return kErrGeneric;
     if (b->nFrames == 0) return 0;
     { size_t const e = zsa_check_device(b, cdict ? cdict->device : -1); if (e) return e; }
@@ -418,23 +440,28 @@ extern "C" size_t zsa_compress_enqueue(zsa_batch* b, int level, const zsa_CDict*
     ZsaEncLayout const L = zsa_enc_layout(b->sizesOnDevice ? ZSA_BLOCKSIZE_MAX : b->maxSrcSize, b->planHtBytes);
     size_t const ldsPerWG = sizeof(ZsaEncShared) + 64;
     unsigned grid = zsa_grid(b, ldsPerWG);
-    if (L.stride > ((u64)8 << 20) && (size_t)grid * L.stride > b->encScratchBytes) {
-        // large tables (high levels on large inputs): the workspace of a full grid may not fit; the launch then keeps
-        // fewer frames in flight -- at most half of what the device has free
+    if ((size_t)grid * L.stride > b->encScratchBytes) {
+        // the workspace of a full grid may not fit what the device has free (large tables of high levels, a GPU that is partly
+        // in use): the launch then keeps fewer frames in flight -- at most half of what is free plus what the batch holds
         size_t freeB = 0, totalB = 0;
         if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) { (void)hipGetLastError(); freeB = 0; }
         size_t const budget = (freeB + b->encScratchBytes) / 2;
         if ((size_t)grid * L.stride > budget) { size_t const g = budget / L.stride; grid = (unsigned)(g ? g : 1); }
     }
     {   // workspace: grows when a launch needs more than the batch has held so far; steady-state enqueues allocate nothing
-        size_t const need = (size_t)grid * L.stride;
+        size_t need = (size_t)grid * L.stride;
         if (need > b->encScratchBytes) {
             if (b->d_encScratch) { (void)hipFree(b->d_encScratch); b->d_encScratch = NULL; b->encScratchBytes = 0; }   // (waits for launches using it)
-            if (hipMalloc((void**)&b->d_encScratch, need) != hipSuccess) {
-                (void)hipGetLastError();
+            bool got = false;
+            for (int attempt = 0; attempt < 2 && !got; attempt++) {   // a refused allocation is tried once more with half the frames in flight
+                if (attempt) { if (grid < 2) break; grid = (grid + 1) / 2; need = (size_t)grid * L.stride; }
+                got = !zsa_forced_alloc_failure() && hipMalloc((void**)&b->d_encScratch, need) == hipSuccess;
+                if (!got) (void)hipGetLastError();
+            }
+            if (!got) {
                 fprintf(stderr, "libzstd_amd: device allocation of the compression workspace failed (%zu bytes)\n", need);
                 b->d_encScratch = NULL;
-                return (size_t)ZSA_ERR(ZSA_memory_allocation);
+                return zsa_fail(ZSA_EF_MEMORY, (size_t)ZSA_ERR(ZSA_memory_allocation));
             }
             b->encScratchBytes = need;
         }
@@ -473,6 +500,7 @@ extern "C" size_t zsa_compress_enqueue(zsa_batch* b, int level, const zsa_CDict*
 }
 extern "C" size_t zsa_decompress_enqueue(zsa_batch* b, const zsa_DDict* ddict, void* stream)
 {
+    t_engineFailure = ZSA_EF_NONE;
     if (!b) return kErrGeneric;
     if (b->nFrames == 0) return 0;
     { size_t const e = zsa_check_device(b, ddict ? ddict->device : -1); if (e) return e; }
@@ -523,9 +551,31 @@ static __device__ __align__(256) u8 zsa_na_scratch[256 + (size_t)ZSA_NA_WORKGROU
 #define ZSA_NA_MAX_DEVICES 64
 static u8* g_naPtr[ZSA_NA_MAX_DEVICES];
 static std::mutex g_naMutex;
+static u8* zsa_na_address(int dev)
+{
+    if (dev < 0 || dev >= ZSA_NA_MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> g(g_naMutex);
+    if (!g_naPtr[dev]) {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != dev) { (void)hipGetLastError(); return nullptr; }   // (the lookup answers for the current device)
+        void* p = nullptr;
+        hipError_t const e = hipGetSymbolAddress(&p, HIP_SYMBOL(zsa_na_scratch));
+        if (e != hipSuccess) { fprintf(stderr, "libzstd_amd: hipGetSymbolAddress(zsa_na_scratch) failed: %s\n", hipGetErrorString(e)); (void)hipGetLastError(); return nullptr; }
+        g_naPtr[dev] = (u8*)p;
+    }
+    return g_naPtr[dev];
+}
+// warm-up for callers that make their first call under graph capture: resolves the workspace address on the current device
+extern "C" size_t zsa_noalloc_prepare(void)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return zsa_fail(ZSA_EF_NO_DEVICE, kErrGeneric); }
+    return zsa_na_address(dev) ? 0 : zsa_fail(ZSA_EF_RUNTIME, kErrGeneric);
+}
 extern "C" size_t zsa_decompress_frames_noalloc(const zsa_frame* d_frames, uint64_t* d_results, size_t nFrames, const zsa_DDict* ddict, void* stream)
 {
     static_assert(sizeof(zsa_frame) == sizeof(ZsaFrameDesc), "zsa_frame is the kernels' frame descriptor");
+    t_engineFailure = ZSA_EF_NONE;
     if (nFrames == 0) return 0;
     if (!d_frames || !d_results) return kErrGeneric;
     if (nFrames > ZSA_NA_MAX_FRAMES) {
@@ -533,18 +583,12 @@ extern "C" size_t zsa_decompress_frames_noalloc(const zsa_frame* d_frames, uint6
         return (size_t)ZSA_ERR(ZSA_parameter_outOfBound);
     }
     int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ZSA_NA_MAX_DEVICES) { fprintf(stderr, "libzstd_amd: no usable HIP device -- this library has no CPU path\n"); return kErrGeneric; }
-    if (ddict && ddict->device != dev) { fprintf(stderr, "libzstd_amd: device mismatch: dictionary on device %d, current device %d\n", ddict->device, dev); return (size_t)ZSA_ERR(ZSA_stage_wrong); }
-    u8* ptr;
-    {   // the array's address on THIS device, looked up once per device (the name itself is only a host-side handle)
-        std::lock_guard<std::mutex> g(g_naMutex);
-        if (!g_naPtr[dev]) {
-            void* p = nullptr;
-            HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(zsa_na_scratch)));
-            g_naPtr[dev] = (u8*)p;
-        }
-        ptr = g_naPtr[dev];
-    }
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ZSA_NA_MAX_DEVICES) { (void)hipGetLastError(); fprintf(stderr, "libzstd_amd: no usable HIP device -- this library has no CPU path\n"); return zsa_fail(ZSA_EF_NO_DEVICE, kErrGeneric); }
+    if (ddict && ddict->device != dev) { fprintf(stderr, "libzstd_amd: device mismatch: dictionary on device %d, current device %d\n", ddict->device, dev); return zsa_fail(ZSA_EF_DEVICE_MISMATCH, (size_t)ZSA_ERR(ZSA_stage_wrong)); }
+    // the array's address on THIS device (the name itself is only a host-side handle): looked up once per device, by
+    // zsa_batch_create / zsa_createDDict / zsa_noalloc_prepare, or here on a first call that none of them preceded
+    u8* const ptr = zsa_na_address(dev);
+    if (!ptr) return zsa_fail(ZSA_EF_RUNTIME, kErrGeneric);
     unsigned const grid = (unsigned)(nFrames < ZSA_NA_WORKGROUPS ? nFrames : ZSA_NA_WORKGROUPS);
     HIPCHK(hipMemsetAsync(ptr, 0, 256, (hipStream_t)stream));   // the work counter starts at zero; the rest is write-before-read
     hipLaunchKernelGGL(zsa_k_decompress, dim3(grid), dim3(64), 0, (hipStream_t)stream,
@@ -560,21 +604,27 @@ extern "C" size_t zsa_decompress_frames_noalloc(const zsa_frame* d_frames, uint6
 // gone when thread-local destructors run, so from then on everything is left to it.
 static bool g_zsaExiting = false;
 static void zsa_mark_exit() { g_zsaExiting = true; }
+#define ZSA_MAX_SUBS 8          // a large host batch runs as up to this many sub-batches, each on a stream of its own
 struct ZsaStage {
     u8 *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr;
-    u64 *h_meta = nullptr, *d_meta = nullptr;   // per frame (offset in d_out, packed offset, size): large batches only
+    u64 *h_meta = nullptr, *d_meta = nullptr;   // per frame: pack records (large batches only)
     size_t inCap = 0, outCap = 0, metaCap = 0;
-    zsa_batch* batch = nullptr;
-    hipStream_t stream = nullptr;
+    zsa_batch* batch[ZSA_MAX_SUBS] = {};
+    hipStream_t stream[ZSA_MAX_SUBS] = {};
+    hipEvent_t uploaded[ZSA_MAX_SUBS] = {};
     int device = -1;
+    void forget()
+    {
+        h_in = h_out = d_in = d_out = nullptr; h_meta = d_meta = nullptr; inCap = outCap = metaCap = 0;
+        for (int k = 0; k < ZSA_MAX_SUBS; k++) { batch[k] = nullptr; stream[k] = nullptr; uploaded[k] = nullptr; }
+    }
     void release()
     {
         if (h_in) { (void)hipHostFree(h_in); (void)hipFree(d_in); }
         if (h_out) { (void)hipHostFree(h_out); (void)hipFree(d_out); }
         if (h_meta) { (void)hipHostFree(h_meta); (void)hipFree(d_meta); }
-        if (batch) zsa_batch_free(batch);
-        if (stream) (void)hipStreamDestroy(stream);
-        h_in = h_out = d_in = d_out = nullptr; h_meta = d_meta = nullptr; inCap = outCap = metaCap = 0; batch = nullptr; stream = nullptr;
+        for (int k = 0; k < ZSA_MAX_SUBS; k++) { if (batch[k]) zsa_batch_free(batch[k]); if (stream[k]) (void)hipStreamDestroy(stream[k]); if (uploaded[k]) (void)hipEventDestroy(uploaded[k]); }
+        forget();
     }
     ~ZsaStage()
     {
@@ -591,79 +641,135 @@ static thread_local ZsaStage t_stage;
 // freed by ZSTD_freeCCtx/ZSTD_freeDCtx: zstd_ctx.go:43-51).
 extern "C" void zsa_thread_release(void) { if (t_stage.device != -1) { t_stage.release(); t_stage.device = -1; } }
 
-static size_t zsa_stage_reserve(ZsaStage& st, size_t inBytes, size_t outBytes, size_t nFrames, size_t metaBytes)
+// ---- pinned host memory handed out by the library: buffers a caller takes from zsa_host_alloc are known to be page-locked
+// and mapped into every GPU's address space, so a host batch whose payloads (or destinations) all lie inside them skips the
+// staging copy on that side and the GPU moves the bytes itself.  (The ranges are kept here: asking the runtime about
+// every pointer of a batch would cost more than the copy it saves.)
+static std::mutex g_pinMutex;
+static std::map<uintptr_t, size_t> g_pinned;     // base -> bytes
+extern "C" void* zsa_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (bytes == 0) bytes = 1;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); t_engineFailure = ZSA_EF_MEMORY; return nullptr; }
+    std::lock_guard<std::mutex> g(g_pinMutex);
+    g_pinned[(uintptr_t)p] = bytes;
+    return p;
+}
+extern "C" void zsa_host_free(void* p)
+{
+    if (!p) return;
+    {   std::lock_guard<std::mutex> g(g_pinMutex);
+        g_pinned.erase((uintptr_t)p);
+    }
+    (void)hipHostFree(p);
+}
+// every non-empty range [ptr[i], ptr[i] + len[i]) lies inside memory from zsa_host_alloc
+static bool zsa_all_pinned(const void* const* ptr, const size_t* len, size_t n)
+{
+    std::lock_guard<std::mutex> g(g_pinMutex);
+    if (g_pinned.empty()) return false;
+    uintptr_t lo = 0, hi = 0;                    // the range that held the previous pointer (batches come from one slab as a rule)
+    for (size_t i = 0; i < n; i++) {
+        if (len[i] == 0) continue;
+        uintptr_t const a = (uintptr_t)ptr[i];
+        if (!(a >= lo && a + len[i] <= hi)) {
+            auto it = g_pinned.upper_bound(a);
+            if (it == g_pinned.begin()) return false;
+            --it;
+            lo = it->first; hi = lo + it->second;
+            if (!(a >= lo && a + len[i] <= hi)) return false;
+        }
+    }
+    return true;
+}
+
+static size_t zsa_stage_reserve(ZsaStage& st, size_t inBytes, size_t outBytes, const size_t* subFrames, unsigned nSubs, size_t metaBytes, bool pinIn, bool pinOut)
 {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) { fprintf(stderr, "libzstd_amd: no usable HIP device -- this library has no CPU path\n"); return kErrGeneric; }
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); fprintf(stderr, "libzstd_amd: no usable HIP device -- this library has no CPU path\n"); return zsa_fail(ZSA_EF_NO_DEVICE, kErrGeneric); }
     if (st.device != dev) {   // first use on this thread, or the thread moved to another device: staging is per device
         if (st.device != -1) {   // (what it holds belongs to the old device)
             int const old = st.device;
             if (hipSetDevice(old) == hipSuccess) { st.release(); (void)hipSetDevice(dev); }
-            else { st.h_in = st.h_out = st.d_in = st.d_out = nullptr; st.h_meta = st.d_meta = nullptr; st.inCap = st.outCap = st.metaCap = 0; st.batch = nullptr; st.stream = nullptr; }
+            else st.forget();
         }
         static std::once_flag once;
         std::call_once(once, [] { atexit(zsa_mark_exit); });
-        HIPCHK(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
         st.device = dev;
     }
-    if (inBytes > st.inCap) {
-        if (st.h_in) { (void)hipHostFree(st.h_in); (void)hipFree(st.d_in); st.h_in = st.d_in = nullptr; st.inCap = 0; }
-        size_t const cap = inBytes + (inBytes >> 2) + 4096;
-        if (hipHostMalloc((void**)&st.h_in, cap, hipHostMallocDefault) != hipSuccess || hipMalloc((void**)&st.d_in, cap) != hipSuccess) return kErrMemory;
-        st.inCap = cap;
-    }
-    if (outBytes > st.outCap) {
-        if (st.h_out) { (void)hipHostFree(st.h_out); (void)hipFree(st.d_out); st.h_out = st.d_out = nullptr; st.outCap = 0; }
-        size_t const cap = outBytes + (outBytes >> 2) + 4096;
-        if (hipHostMalloc((void**)&st.h_out, cap, hipHostMallocDefault) != hipSuccess || hipMalloc((void**)&st.d_out, cap) != hipSuccess) return kErrMemory;
-        st.outCap = cap;
-    }
+    for (unsigned k = 0; k < nSubs; k++) if (!st.stream[k]) { HIPCHK(hipStreamCreateWithFlags(&st.stream[k], hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&st.uploaded[k], hipEventDisableTiming)); }
+    bool const forced = zsa_forced_alloc_failure();
+    // (a side whose bytes the GPU moves itself needs no pinned staging copy, only the device buffer)
+    auto const grow = [&](u8*& h, u8*& d, size_t& cap, size_t bytes, bool needHost) -> bool {
+        if (bytes <= cap && (!needHost || h)) return true;
+        if (h) (void)hipHostFree(h);
+        if (d) (void)hipFree(d);
+        h = d = nullptr; cap = 0;
+        size_t const want = bytes + (bytes >> 2) + 4096;
+        if (forced || hipMalloc((void**)&d, want) != hipSuccess) { (void)hipGetLastError(); d = nullptr; return false; }
+        if (needHost && hipHostMalloc((void**)&h, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d); h = d = nullptr; return false; }
+        cap = want;
+        return true;
+    };
+    if (!grow(st.h_in, st.d_in, st.inCap, inBytes, !pinIn)) return zsa_fail(ZSA_EF_MEMORY, kErrMemory);
+    if (!grow(st.h_out, st.d_out, st.outCap, outBytes, !pinOut)) return zsa_fail(ZSA_EF_MEMORY, kErrMemory);
     if (metaBytes > st.metaCap) {
         if (st.h_meta) { (void)hipHostFree(st.h_meta); (void)hipFree(st.d_meta); st.h_meta = st.d_meta = nullptr; st.metaCap = 0; }
         size_t const cap = metaBytes + (metaBytes >> 2) + 4096;
-        if (hipHostMalloc((void**)&st.h_meta, cap, hipHostMallocDefault) != hipSuccess || hipMalloc((void**)&st.d_meta, cap) != hipSuccess) return kErrMemory;
+        if (forced || hipHostMalloc((void**)&st.h_meta, cap, hipHostMallocDefault) != hipSuccess || hipMalloc((void**)&st.d_meta, cap) != hipSuccess) { (void)hipGetLastError(); return zsa_fail(ZSA_EF_MEMORY, kErrMemory); }
         st.metaCap = cap;
     }
-    if (!st.batch || st.batch->maxFrames < nFrames) {
-        if (st.batch) zsa_batch_free(st.batch);
-        size_t const cap = nFrames + (nFrames >> 2);   // sized to the request, geometric growth: a thread that compresses one
-        st.batch = zsa_batch_create(cap);              // payload at a time holds one workgroup's workspace, not a chip's
-        if (!st.batch) return kErrMemory;
+    for (unsigned k = 0; k < nSubs; k++) {
+        if (!st.batch[k] || st.batch[k]->maxFrames < subFrames[k]) {
+            if (st.batch[k]) zsa_batch_free(st.batch[k]);
+            size_t const cap = subFrames[k] + (subFrames[k] >> 2);   // sized to the request, geometric growth: a thread that compresses one
+            st.batch[k] = forced ? nullptr : zsa_batch_create(cap);   // payload at a time holds one workgroup's workspace, not a chip's
+            if (!st.batch[k]) return zsa_fail(ZSA_EF_MEMORY, kErrMemory);
+        }
     }
     return 0;
 }
 
-// ---- large host batches: the copies between the caller's (pageable) buffers and the pinned staging buffers are what a
-// host batch spends most of its time on, so from ZSA_PAR_MIN_BYTES on they are made by a few helper threads, piece by
-// piece, while the pieces already staged cross PCIe; compressed output is packed on the device first, so that only the
-// bytes produced travel back.  Helper threads make no HIP calls.  ZSTD_AMD_COPY_THREADS (default 4, 1 = none) sets their number.
+// ---- large host batches.  What a host batch spends its time on is moving bytes: caller's buffers -> pinned staging -> device,
+// and back.  So (1) from ZSA_PAR_MIN_BYTES on the copies between the caller's (pageable) buffers and the pinned staging are
+// made by a few helper threads, piece by piece, while the pieces already staged cross PCIe; (2) the batch is cut into up to
+// ZSA_MAX_SUBS sub-batches, each with its own zsa_batch and stream, so that the upload of sub-batch k + 1, the kernel of
+// sub-batch k and the download of sub-batch k - 1 run at the same time; (3) compressed output is packed on the device first,
+// so that only the bytes produced travel back; (4) payloads / decompression destinations in memory from zsa_host_alloc cross
+// PCIe straight from / into the caller's buffers, with no staging copy on that side.  Helper threads make no HIP calls.
+// ZSTD_AMD_COPY_THREADS (default 8, 1 = none) sets their number.
 #define ZSA_PAR_MIN_BYTES ((size_t)8 << 20)
+#define ZSA_SUB_MIN_BYTES ((size_t)24 << 20)     // a sub-batch is worth its launch from about this many staged bytes on
 static unsigned zsa_copy_threads()
 {
-    static unsigned const conf = [] { const char* e = getenv("ZSTD_AMD_COPY_THREADS"); int const v = e ? atoi(e) : 4; return (unsigned)(v < 1 ? 1 : (v > 16 ? 16 : v)); }();
+    static unsigned const conf = [] { const char* e = getenv("ZSTD_AMD_COPY_THREADS"); int const v = e ? atoi(e) : 8; return (unsigned)(v < 1 ? 1 : (v > 16 ? 16 : v)); }();
     return conf;
 }
-// frames [0, n) cut into pieces of about equal staged size: piece p = frames [cut[p], cut[p + 1])
-static std::vector<size_t> zsa_cut_pieces(const std::vector<size_t>& off, size_t total, size_t n, size_t pieces)
+static unsigned zsa_max_subs()
 {
-    std::vector<size_t> cut; cut.push_back(0);
+    static unsigned const conf = [] { const char* e = getenv("ZSTD_AMD_SUBS"); int const v = e ? atoi(e) : 4; return (unsigned)(v < 1 ? 1 : (v > ZSA_MAX_SUBS ? ZSA_MAX_SUBS : v)); }();
+    return conf;
+}
+// frames [lo, hi) cut into pieces of about equal staged size: piece p = frames [cut[p], cut[p + 1])
+static std::vector<size_t> zsa_cut_pieces(const std::vector<size_t>& off, size_t lo, size_t hi, size_t pieces)
+{
+    std::vector<size_t> cut; cut.push_back(lo);
+    size_t const total = off[hi] - off[lo];
     for (size_t p = 1; p < pieces; p++) {
-        size_t const want = total / pieces * p;
+        size_t const want = off[lo] + total / pieces * p;
         size_t f = cut.back();
-        while (f < n && off[f] < want) f++;
-        if (f > cut.back() && f < n) cut.push_back(f);
+        while (f < hi && off[f] < want) f++;
+        if (f > cut.back() && f < hi) cut.push_back(f);
     }
-    cut.push_back(n);
+    cut.push_back(hi);
     return cut;
 }
-// Runs copyFrame(i) for every frame of every piece on `threads` helper threads: helper w takes pieces w, w + threads, ...; a
-// piece is started once ready(p) has returned (called on the helper) and reported through done(p) (called on the caller's
-// thread, in piece order, as soon as the piece is complete).
 struct ZsaPieceFlags {
     std::vector<std::atomic<int>> f;
     explicit ZsaPieceFlags(size_t n) : f(n) { for (auto& x : f) x.store(0, std::memory_order_relaxed); }
-    void set(size_t p) { f[p].store(1, std::memory_order_release); }
-    void wait(size_t p) { unsigned spins = 0; while (!f[p].load(std::memory_order_acquire)) { if (++spins > 64) std::this_thread::yield(); } }
+    void set(size_t p, int v = 1) { f[p].store(v, std::memory_order_release); }
+    int wait(size_t p) { unsigned spins = 0; int v; while (!(v = f[p].load(std::memory_order_acquire))) { if (++spins > 64) std::this_thread::yield(); } return v; }
 };
 
 // packs the produced bytes of every frame back to back (16-byte aligned offsets): one workgroup per frame
@@ -678,119 +784,251 @@ __global__ void __launch_bounds__(256) zsa_k_pack(const u8* __restrict__ from, u
     for (u64 k = threadIdx.x; k < q; k += 256) b[k] = a[k];
     for (u64 k = (q << 4) + threadIdx.x; k < size; k += 256) to[dstOff + k] = from[srcOff + k];
 }
-
+static bool zsa_trace_on() { static int const on = getenv("ZSTD_AMD_TRACE") ? 1 : 0; return on != 0; }
+#define ZSA_TRACE(...) do { if (zsa_trace_on()) { fprintf(stderr, "[zsa %8.3f ms] ", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count()); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); } } while (0)
 static size_t zsa_run_host_batch(bool compress, const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCapacity,
                                  size_t* outSize, size_t n, int level, const zsa_CDict* cd, const zsa_DDict* dd)
 {
+    auto const t0_ = std::chrono::steady_clock::now();
+    t_engineFailure = ZSA_EF_NONE;
     if (n == 0) return 0;
     ZsaStage& st = t_stage;
-    // layout: inputs and outputs packed back to back, 16-byte aligned, with 32 bytes of slack after each input
-    std::vector<size_t> inOff(n + 1), outOff(n + 1);
+    // Payloads / destinations in memory from zsa_host_alloc cross PCIe straight from / into the caller's buffers, one DMA
+    // copy per RUN of frames that lie one behind the other there: the device slots of a run mirror its layout on the host.
+    // (Compressed output is sparse in its bound-sized slots, so compress destinations always go through the packed staging.)
+    bool pinIn = zsa_all_pinned(src, srcSize, n), pinOut = !compress && zsa_all_pinned((const void* const*)dst, dstCapacity, n);
+    // layout: inputs and outputs back to back, 16-byte aligned (pinned side: congruent to the host address modulo 16), with 32
+    // bytes of slack after each input.  A compress slot holds ZSTD_compressBound(srcSize) bytes whatever the caller's capacity: as
+    // ZSTD_compress does, a destination below the bound is served when the frame fits it (zstd_compress.c:5090-5111 has no
+    // bound check; the kernels keep the bound as their contract)
+    std::vector<size_t> inOff(n + 1), outOff(n + 1), devCap(n);
+    std::vector<char> inRun(n, 0), outRun(n, 0);            // frame i continues the run of frame i - 1
     size_t inBytes = 0, outBytes = 0;
-    for (size_t i = 0; i < n; i++) {
-        inOff[i] = inBytes; inBytes += (srcSize[i] + 32 + 15) & ~(size_t)15;
-        outOff[i] = outBytes; outBytes += (dstCapacity[i] + 15) & ~(size_t)15;
+    auto const layout = [&]() {
+        size_t runsIn = 0, runsOut = 0;
+        inBytes = outBytes = 0;
+        for (size_t i = 0; i < n; i++) {
+            inRun[i] = outRun[i] = 0;
+            if (pinIn) {
+                uintptr_t const p = (uintptr_t)src[i], prev = i ? (uintptr_t)src[i - 1] : 0;
+                if (i && srcSize[i - 1] && srcSize[i] && p >= prev + srcSize[i - 1] && p - (prev + srcSize[i - 1]) <= 4096) { inRun[i] = 1; inOff[i] = inOff[i - 1] + (p - prev); }
+                else { inOff[i] = ((inBytes + 15) & ~(size_t)15) + (p & 15); runsIn++; }
+                if (inOff[i] + srcSize[i] + 48 > inBytes) inBytes = inOff[i] + srcSize[i] + 48;
+            } else { inOff[i] = inBytes; inBytes += (srcSize[i] + 32 + 15) & ~(size_t)15; }
+            size_t c = dstCapacity[i];
+            if (compress) { size_t const bnd = zsa_compressBound(srcSize[i]); if (!zsa_isError(bnd) && c < bnd) c = bnd; }
+            devCap[i] = c;
+            if (pinOut) {   // (a run is copied back whole, so it may hold nothing but the frames' own destinations: exactly adjacent)
+                uintptr_t const p = (uintptr_t)dst[i], prev = i ? (uintptr_t)dst[i - 1] : 0;
+                if (i && dstCapacity[i - 1] && c && p == prev + dstCapacity[i - 1]) { outRun[i] = 1; outOff[i] = outOff[i - 1] + dstCapacity[i - 1]; }
+                else { outOff[i] = ((outBytes + 15) & ~(size_t)15) + (p & 15); runsOut++; }
+                outBytes = outOff[i] + c;
+            } else { outOff[i] = outBytes; outBytes += (c + 15) & ~(size_t)15; }
+        }
+        inBytes = (inBytes + 15) & ~(size_t)15; outBytes = (outBytes + 15) & ~(size_t)15;
+        inOff[n] = inBytes; outOff[n] = outBytes;
+        // scattered buffers (compressed frames in bound-sized slots, say) would mean one small copy per frame: staged instead
+        bool const manyIn = pinIn && runsIn > n / 16 + 16, manyOut = pinOut && runsOut > n / 16 + 16;
+        if (manyIn) pinIn = false;
+        if (manyOut) pinOut = false;
+        return manyIn || manyOut;
+    };
+    if (layout()) (void)layout();
+    bool const large = n >= 8 && inBytes + outBytes >= ZSA_PAR_MIN_BYTES;
+    unsigned const T = large ? zsa_copy_threads() : 1;
+    // sub-batches: frames [sub[k], sub[k + 1]), about equal in staged bytes
+    std::vector<size_t> sub;
+    {   size_t S = large ? (inBytes + outBytes) / ZSA_SUB_MIN_BYTES : 1;
+        if (S > zsa_max_subs()) S = zsa_max_subs();
+        if (S > n / 8) S = n / 8;
+        if (S < 1) S = 1;
+        std::vector<size_t> both(n + 1);
+        for (size_t i = 0; i <= n; i++) both[i] = inOff[i] + outOff[i];
+        sub = zsa_cut_pieces(both, 0, n, S);
     }
-    inOff[n] = inBytes; outOff[n] = outBytes;
-    unsigned const T = (n >= 8 && inBytes + outBytes >= ZSA_PAR_MIN_BYTES) ? zsa_copy_threads() : 1;
-    { size_t const e = zsa_stage_reserve(st, inBytes, outBytes, n, T > 1 ? 3 * n * sizeof(u64) : 0); if (e) return e; }
-    for (size_t i = 0; i < n; i++) zsa_batch_set_frame(st.batch, i, st.d_in + inOff[i], srcSize[i], st.d_out + outOff[i], dstCapacity[i]);
-    if (T == 1) {
+    unsigned const S = (unsigned)sub.size() - 1;
+    size_t subFrames[ZSA_MAX_SUBS] = {};
+    for (unsigned k = 0; k < S; k++) subFrames[k] = sub[k + 1] - sub[k];
+    if (!large) pinIn = pinOut = false;                      // (small calls: one staging copy each way, one wait)
+    { size_t const e = zsa_stage_reserve(st, inBytes, outBytes, subFrames, S, large ? 3 * n * sizeof(u64) : 0, pinIn, pinOut); if (e) return e; }
+    for (unsigned k = 0; k < S; k++)
+        for (size_t i = sub[k]; i < sub[k + 1]; i++) zsa_batch_set_frame(st.batch[k], i - sub[k], st.d_in + inOff[i], srcSize[i], st.d_out + outOff[i], devCap[i]);
+    auto const finish = [&](size_t i) {   // a frame that does not fit the caller's destination: the reference's error
+        if (!zsa_isError(outSize[i]) && outSize[i] > dstCapacity[i]) outSize[i] = (size_t)ZSA_ERR(ZSA_dstSize_tooSmall);
+    };
+    if (!large) {
+        hipStream_t const q = st.stream[0];
         for (size_t i = 0; i < n; i++) if (srcSize[i]) memcpy(st.h_in + inOff[i], src[i], srcSize[i]);
-        HIPCHK(hipMemcpyAsync(st.d_in, st.h_in, inBytes, hipMemcpyHostToDevice, st.stream));
-    } else {   // helpers stage piece after piece; each piece crosses PCIe while the next ones are being staged
-        std::vector<size_t> const cut = zsa_cut_pieces(inOff, inBytes, n, (size_t)T * 4);
-        size_t const P = cut.size() - 1;
+        HIPCHK(hipMemcpyAsync(st.d_in, st.h_in, inBytes, hipMemcpyHostToDevice, q));
+        { size_t const e = zsa_batch_upload(st.batch[0], n, q); if (e) return e; }
+        { size_t const e = compress ? zsa_compress_enqueue(st.batch[0], level, cd, q) : zsa_decompress_enqueue(st.batch[0], dd, q); if (e) return e; }
+        // small calls (the one-shot entry points): the whole output region travels back with the result words, one wait for both
+        bool const eager = outBytes <= ((size_t)256 << 10);
+        if (eager) HIPCHK(hipMemcpyAsync(st.h_out, st.d_out, outBytes, hipMemcpyDeviceToHost, q));
+        { size_t const e = zsa_batch_results(st.batch[0], outSize, q); if (e) return e; }
+        for (size_t i = 0; i < n; i++) finish(i);
+        if (!eager) {   // copy back only the span that was produced
+            size_t lo = (size_t)-1, hi = 0;
+            for (size_t i = 0; i < n; i++) if (!zsa_isError(outSize[i]) && outSize[i]) {
+                if (outOff[i] < lo) lo = outOff[i];
+                if (outOff[i] + outSize[i] > hi) hi = outOff[i] + outSize[i];
+            }
+            if (hi <= lo) return 0;
+            HIPCHK(hipMemcpyAsync(st.h_out + lo, st.d_out + lo, hi - lo, hipMemcpyDeviceToHost, q));
+            HIPCHK(hipStreamSynchronize(q));
+        }
+        for (size_t i = 0; i < n; i++) if (!zsa_isError(outSize[i]) && outSize[i]) memcpy(dst[i], st.h_out + outOff[i], outSize[i]);
+        return 0;
+    }
+
+    // ---- large batch
+    ZSA_TRACE("%s: %zu frames, %zu MiB in, %zu MiB out slots, %u sub-batches, %u helpers, pinned in/out %d/%d", compress ? "compress" : "decompress", n, inBytes >> 20, outBytes >> 20, S, T, (int)pinIn, (int)pinOut);
+    u64* const h_pk = st.h_meta; u64* const d_pk = st.d_meta;   // 3 words per frame for zsa_k_pack
+    size_t firstError = 0;
+    // input side, sub-batch after sub-batch; the kernel of each is enqueued as soon as its input is on its way
+    {   std::vector<std::vector<size_t>> cuts(S);
+        std::vector<size_t> pieceBase(S + 1, 0);
+        for (unsigned k = 0; k < S; k++) { cuts[k] = zsa_cut_pieces(inOff, sub[k], sub[k + 1], pinIn ? 1 : (size_t)T); pieceBase[k + 1] = pieceBase[k] + cuts[k].size() - 1; }
+        size_t const P = pieceBase[S];
         ZsaPieceFlags staged(P);
         std::vector<std::thread> helpers;
+        unsigned made = 0;
         u8* const h_in = st.h_in;
-        auto const work = [&](unsigned w) {
+        auto const work = [&](unsigned w) {   // helper w stages pieces w, w + T, ... in order (pieces are numbered across sub-batches)
             for (size_t p = w; p < P; p += T) {
-                for (size_t i = cut[p]; i < cut[p + 1]; i++) if (srcSize[i]) memcpy(h_in + inOff[i], src[i], srcSize[i]);
+                unsigned k = 0; while (p >= pieceBase[k + 1]) k++;
+                size_t const q = p - pieceBase[k];
+                for (size_t i = cuts[k][q]; i < cuts[k][q + 1]; i++) if (srcSize[i]) memcpy(h_in + inOff[i], src[i], srcSize[i]);
                 staged.set(p);
             }
         };
-        unsigned made = 0;
-        try { for (; made < T; made++) helpers.emplace_back(work, made); } catch (...) { }
-        for (unsigned w = made; w < T; w++) work(w);   // (a helper that could not be started: its share is copied here)
-        hipError_t err = hipSuccess;
-        for (size_t p = 0; p < P; p++) {
-            staged.wait(p);
-            size_t const lo = inOff[cut[p]], hi = inOff[cut[p + 1]];
-            if (err == hipSuccess && hi > lo) err = hipMemcpyAsync(st.d_in + lo, st.h_in + lo, hi - lo, hipMemcpyHostToDevice, st.stream);
+        if (!pinIn) {
+            try { for (; made < T; made++) helpers.emplace_back(work, made); } catch (...) { }
+            for (unsigned w = made; w < T; w++) work(w);   // (a helper that could not be started: its share is copied here)
+        }
+        for (unsigned k = 0; k < S && !firstError; k++) {
+            hipStream_t const q = st.stream[k];
+            size_t const a = sub[k], b = sub[k + 1];
+            hipError_t err = hipSuccess;
+            // uploads go one after the other (sub-batch k + 1's waits for sub-batch k's), so that kernel k starts as early as it can
+            if (k && pinIn) err = hipStreamWaitEvent(q, st.uploaded[k - 1], 0);
+            if (pinIn && err == hipSuccess) {   // one DMA copy per run, straight from the caller's memory
+                for (size_t i = a; i < b && err == hipSuccess; ) {
+                    size_t j = i + 1;
+                    while (j < b && inRun[j]) j++;
+                    size_t const bytes = ((uintptr_t)src[j - 1] + srcSize[j - 1]) - (uintptr_t)src[i];
+                    if (bytes) err = hipMemcpyAsync(st.d_in + inOff[i], src[i], bytes, hipMemcpyHostToDevice, q);
+                    i = j;
+                }
+                if (err == hipSuccess) err = hipEventRecord(st.uploaded[k], q);
+            } else {
+                for (size_t p = pieceBase[k]; p < pieceBase[k + 1]; p++) {
+                    staged.wait(p);
+                    size_t const c0 = cuts[k][p - pieceBase[k]], c1 = cuts[k][p - pieceBase[k] + 1];
+                    size_t const lo = inOff[c0], hi = inOff[c1];
+                    if (err == hipSuccess && hi > lo) err = hipMemcpyAsync(st.d_in + lo, st.h_in + lo, hi - lo, hipMemcpyHostToDevice, q);
+                }
+            }
+            if (err != hipSuccess) { fprintf(stderr, "libzstd_amd: host batch upload failed: %s\n", hipGetErrorString(err)); (void)hipGetLastError(); firstError = zsa_fail(ZSA_EF_RUNTIME, kErrGeneric); break; }
+            size_t e = zsa_batch_upload(st.batch[k], b - a, q);
+            if (!e) e = compress ? zsa_compress_enqueue(st.batch[k], level, cd, q) : zsa_decompress_enqueue(st.batch[k], dd, q);
+            if (!e && pinOut) {   // one DMA copy per run, straight into the caller's memory (a frame that failed leaves its slot's bytes there)
+                for (size_t i = a; i < b && err == hipSuccess; ) {
+                    size_t j = i + 1;
+                    while (j < b && outRun[j]) j++;
+                    size_t const bytes = ((uintptr_t)dst[j - 1] + dstCapacity[j - 1]) - (uintptr_t)dst[i];
+                    if (bytes) err = hipMemcpyAsync(dst[i], st.d_out + outOff[i], bytes, hipMemcpyDeviceToHost, q);
+                    i = j;
+                }
+                if (err != hipSuccess) { (void)hipGetLastError(); e = zsa_fail(ZSA_EF_RUNTIME, kErrGeneric); }
+            }
+            if (e) firstError = e;
+            ZSA_TRACE("sub-batch %u enqueued", k);
         }
         for (auto& h : helpers) h.join();
-        HIPCHK(err);
+        if (firstError) { for (unsigned k = 0; k < S; k++) (void)hipStreamSynchronize(st.stream[k]); return firstError; }
     }
-    { size_t const e = zsa_batch_upload(st.batch, n, st.stream); if (e) return e; }
-    { size_t const e = compress ? zsa_compress_enqueue(st.batch, level, cd, st.stream) : zsa_decompress_enqueue(st.batch, dd, st.stream); if (e) return e; }
-    // small calls (the one-shot entry points): the whole output region travels back with the result words, one wait for both
-    bool const eager = outBytes <= ((size_t)256 << 10);
-    if (eager) HIPCHK(hipMemcpyAsync(st.h_out, st.d_out, outBytes, hipMemcpyDeviceToHost, st.stream));
-    { size_t const e = zsa_batch_results(st.batch, outSize, st.stream); if (e) return e; }
-    if (eager) {
-        for (size_t i = 0; i < n; i++) if (!zsa_isError(outSize[i]) && outSize[i]) memcpy(dst[i], st.h_out + outOff[i], outSize[i]);
-        return 0;
-    }
-    // copy back only what was produced
-    size_t lo = (size_t)-1, hi = 0, produced = 0;
-    for (size_t i = 0; i < n; i++) if (!zsa_isError(outSize[i]) && outSize[i]) {
-        if (outOff[i] < lo) lo = outOff[i];
-        if (outOff[i] + outSize[i] > hi) hi = outOff[i] + outSize[i];
-        produced += (outSize[i] + 15) & ~(size_t)15;
-    }
-    if (hi <= lo) return 0;
-    if (T == 1) {
-        HIPCHK(hipMemcpyAsync(st.h_out + lo, st.d_out + lo, hi - lo, hipMemcpyDeviceToHost, st.stream));
-        HIPCHK(hipStreamSynchronize(st.stream));
-        for (size_t i = 0; i < n; i++) if (!zsa_isError(outSize[i]) && outSize[i]) memcpy(dst[i], st.h_out + outOff[i], outSize[i]);
-        return 0;
-    }
-    // Where the frames filled less than three quarters of their capacities (compressed output), the produced bytes are first
-    // packed into the input staging buffer on the device -- its content is no longer needed -- and travel from there.
-    std::vector<size_t> hostOff(n + 1);
-    const u8* d_from = st.d_out; u8* h_to = st.h_out;
-    bool const pack = n <= 0xFFFFFFFFu && produced <= st.inCap && produced < (hi - lo) / 4 * 3;
-    if (pack) {
-        size_t at = 0;
-        for (size_t i = 0; i < n; i++) {
-            size_t const sz = (!zsa_isError(outSize[i])) ? outSize[i] : 0;
-            hostOff[i] = at; st.h_meta[3 * i] = outOff[i]; st.h_meta[3 * i + 1] = at; st.h_meta[3 * i + 2] = sz;
-            at += (sz + 15) & ~(size_t)15;
+    // output side: results of sub-batch k (this waits for its kernel), then its bytes -- while the later sub-batches run
+    if (pinOut) {
+        for (unsigned k = 0; k < S; k++) {
+            size_t const e = zsa_batch_results(st.batch[k], outSize + sub[k], st.stream[k]);   // (synchronises the stream: the copies into the destinations are done)
+            if (e && !firstError) firstError = e;
+            ZSA_TRACE("sub-batch %u done", k);
         }
-        hostOff[n] = at;
-        HIPCHK(hipMemcpyAsync(st.d_meta, st.h_meta, 3 * n * sizeof(u64), hipMemcpyHostToDevice, st.stream));
-        hipLaunchKernelGGL(zsa_k_pack, dim3((unsigned)n), dim3(256), 0, st.stream, (const u8*)st.d_out, st.d_in, (const u64*)st.d_meta, (u32)n);
-        HIPCHK(hipGetLastError());
-        d_from = st.d_in; h_to = st.h_in;
-    } else {
-        for (size_t i = 0; i <= n; i++) hostOff[i] = outOff[i];
+        for (size_t i = 0; i < n; i++) finish(i);
+        return firstError;
     }
-    {   std::vector<size_t> const cut = zsa_cut_pieces(hostOff, hostOff[n], n, (size_t)T * 4);
-        size_t const P = cut.size() - 1;
+    {   std::vector<size_t> hostOff(n + 1, 0);                 // where frame i's bytes land in the pinned buffer they travel through
+        std::vector<std::vector<size_t>> cuts(S);
+        std::vector<size_t> pieceBase(S + 1, 0);
+        std::vector<const u8*> hFrom(S, nullptr);
+        // pieces are cut before the sizes are known: by capacity, which bounds what is produced
+        for (unsigned k = 0; k < S; k++) { cuts[k] = zsa_cut_pieces(outOff, sub[k], sub[k + 1], (size_t)T); pieceBase[k + 1] = pieceBase[k] + cuts[k].size() - 1; }
+        size_t const P = pieceBase[S];
         ZsaPieceFlags arrived(P);
         std::vector<std::thread> helpers;
         auto const work = [&](unsigned w) {
             for (size_t p = w; p < P; p += T) {
-                arrived.wait(p);
-                if (arrived.f[p].load(std::memory_order_acquire) < 0) continue;   // (the transfer failed: nothing to hand out)
-                for (size_t i = cut[p]; i < cut[p + 1]; i++) if (!zsa_isError(outSize[i]) && outSize[i]) memcpy(dst[i], h_to + hostOff[i], outSize[i]);
+                if (arrived.wait(p) < 0) continue;             // (the transfer failed: nothing to hand out)
+                unsigned k = 0; while (p >= pieceBase[k + 1]) k++;
+                size_t const q = p - pieceBase[k];
+                const u8* const from = hFrom[k];
+                for (size_t i = cuts[k][q]; i < cuts[k][q + 1]; i++) if (!zsa_isError(outSize[i]) && outSize[i]) memcpy(dst[i], from + hostOff[i], outSize[i]);
             }
         };
         unsigned made = 0;
         try { for (; made < T; made++) helpers.emplace_back(work, made); } catch (...) { }
-        hipError_t err = hipSuccess;
-        for (size_t p = 0; p < P; p++) {
-            size_t const a = hostOff[cut[p]], b = hostOff[cut[p + 1]];
-            if (err == hipSuccess && b > a) err = hipMemcpyAsync(h_to + a, d_from + a, b - a, hipMemcpyDeviceToHost, st.stream);
-            if (err == hipSuccess) err = hipStreamSynchronize(st.stream);
-            arrived.f[p].store(err == hipSuccess ? 1 : -1, std::memory_order_release);
+        for (unsigned k = 0; k < S; k++) {
+            hipStream_t const q = st.stream[k];
+            size_t const a = sub[k], b = sub[k + 1];
+            size_t e = firstError ? firstError : zsa_batch_results(st.batch[k], outSize + a, q);
+            ZSA_TRACE("sub-batch %u results", k);
+            hipError_t err = hipSuccess;
+            if (!e) {
+                size_t produced = 0, span = 0;
+                for (size_t i = a; i < b; i++) { finish(i); if (!zsa_isError(outSize[i]) && outSize[i]) { produced += (outSize[i] + 15) & ~(size_t)15; span = outOff[i] + outSize[i] - outOff[a]; } }
+                // where the frames filled less than three quarters of their slots (compressed output), the produced bytes are first
+                // packed into this sub-batch's part of the input staging buffer -- its content is spent -- and travel from there
+                size_t const inLo = inOff[a], inHi = inOff[b];
+                // (the host side of the packed bytes is the input staging buffer, or the output one when the payloads came from pinned memory)
+                bool const pack = produced <= inHi - inLo && produced <= outOff[b] - outOff[a] && produced < span / 4 * 3;
+                const u8* d_from; u8* h_to;
+                if (pack) {
+                    size_t at = inLo;
+                    for (size_t i = a; i < b; i++) {
+                        size_t const sz = (!zsa_isError(outSize[i])) ? outSize[i] : 0;
+                        hostOff[i] = at; h_pk[3 * i] = outOff[i]; h_pk[3 * i + 1] = at; h_pk[3 * i + 2] = sz;
+                        at += (sz + 15) & ~(size_t)15;
+                    }
+                    err = hipMemcpyAsync(d_pk + 3 * a, h_pk + 3 * a, 3 * (b - a) * sizeof(u64), hipMemcpyHostToDevice, q);
+                    if (err == hipSuccess) { hipLaunchKernelGGL(zsa_k_pack, dim3((unsigned)(b - a)), dim3(256), 0, q, (const u8*)st.d_out, st.d_in, (const u64*)(d_pk + 3 * a), (u32)(b - a)); err = hipGetLastError(); }
+                    d_from = st.d_in;
+                    h_to = pinIn ? st.h_out + outOff[a] - inLo : st.h_in;      // (device offset x <-> host offset x of h_to)
+                } else {
+                    for (size_t i = a; i < b; i++) hostOff[i] = outOff[i];
+                    d_from = st.d_out; h_to = st.h_out;
+                }
+                hFrom[k] = h_to;
+                for (size_t p = pieceBase[k]; p < pieceBase[k + 1]; p++) {
+                    size_t const c0 = cuts[k][p - pieceBase[k]], c1 = cuts[k][p - pieceBase[k] + 1];
+                    // the piece's frames lie in [lo, hi) of the buffer they travel through
+                    size_t lo = (size_t)-1, hi = 0;
+                    for (size_t i = c0; i < c1; i++) if (!zsa_isError(outSize[i]) && outSize[i]) { if (hostOff[i] < lo) lo = hostOff[i]; if (hostOff[i] + outSize[i] > hi) hi = hostOff[i] + outSize[i]; }
+                    if (err == hipSuccess && hi > lo) { err = hipMemcpyAsync(h_to + lo, d_from + lo, hi - lo, hipMemcpyDeviceToHost, q); if (err == hipSuccess) err = hipStreamSynchronize(q); }
+                    arrived.set(p, err == hipSuccess ? 1 : -1);
+                }
+                if (err != hipSuccess) { fprintf(stderr, "libzstd_amd: host batch download failed: %s\n", hipGetErrorString(err)); (void)hipGetLastError(); e = zsa_fail(ZSA_EF_RUNTIME, kErrGeneric); }
+            } else {
+                for (size_t p = pieceBase[k]; p < pieceBase[k + 1]; p++) arrived.set(p, -1);
+            }
+            if (e && !firstError) firstError = e;
+            ZSA_TRACE("sub-batch %u downloaded", k);
         }
         for (unsigned w = made; w < T; w++) work(w);   // (a helper that could not be started: its share is handed out here)
         for (auto& h : helpers) h.join();
-        HIPCHK(err);
+        ZSA_TRACE("handed out");
     }
-    return 0;
+    return firstError;
 }
 
 extern "C" size_t zsa_compress_batch(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCapacity,
@@ -812,4 +1050,3 @@ extern "C" size_t zsa_decompress(void* dst, size_t dstCapacity, const void* src,
     size_t const e = zsa_decompress_batch(&src, &srcSize, &dst, &dstCapacity, &out, 1, nullptr);
     return e ? e : out;
 }
-
