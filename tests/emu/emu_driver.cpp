@@ -4,6 +4,8 @@
 #define ZSA_WAVE_HEADER "zsa_wave_emu.h"
 extern "C" { unsigned long long g_zsa_stat[8]; }
 #define ZSA_STAT(i) do { if (lane == 0) g_zsa_stat[i]++; } while (0)
+extern "C" { void (*g_zsa_seq_hook)(const unsigned long long* seq, unsigned n) = nullptr; }
+#define ZSA_SEQ_HOOK(seq, n) do { wv_sync(); if (lane == 0 && g_zsa_seq_hook) g_zsa_seq_hook((const unsigned long long*)(seq), (n)); wv_sync(); } while (0)
 #include "zsa_common.h"
 #include "zsa_decode.h"
 #ifdef ZSA_EMU_ENCODE
@@ -95,10 +97,13 @@ extern "C" size_t emu_compress(void* dst, size_t cap, const void* src, size_t n,
 }
 
 // parameters resolved from the level as the kernel does (ZSTD_fast .. ZSTD_lazy2 rows)
+static u32* g_emu_ht;
+extern "C" void* emu_last_tables() { return g_emu_ht; }   // the match tables as the last emu_compress_level call left them (debugging)
 extern "C" size_t emu_compress_level(void* dst, size_t cap, const void* src, size_t n, int level)
 {
     static ZsaEncShared S;
     static u32* ht = (u32*)malloc((size_t)5 << 20);
+    g_emu_ht = ht;
     static u64* seq = (u64*)malloc(8 * (32768 + 64));
     static u8* lit = (u8*)malloc(ZSA_BLOCKSIZE_MAX + 128);
     static u8* tmp = (u8*)malloc(ZSA_BLOCKSIZE_MAX * 2 + 512);

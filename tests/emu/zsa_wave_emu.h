@@ -69,6 +69,7 @@ ZSA_DEV unsigned wv_shfl_up(unsigned v, int delta, int line = __builtin_LINE()) 
 ZSA_DEV unsigned wv_shfl_xor(unsigned v, int mask, int line = __builtin_LINE()) { int me = g_emu.cur; const uint64_t* a = emu_collect(v, line); return (unsigned)a[(me ^ mask) & 63]; }
 ZSA_DEV void wv_sync(int line = __builtin_LINE()) { (void)emu_collect(0, line); }
 ZSA_DEV void wv_lds_fence(int line = __builtin_LINE()) { (void)emu_collect(0, line); }
+ZSA_DEV void wv_wave_fence(int line = __builtin_LINE()) { (void)emu_collect(0, line); }
 ZSA_DEV unsigned wv_readlane(unsigned v, int srcLane, int line = __builtin_LINE()) { const uint64_t* a = emu_collect(v, line); return (unsigned)a[srcLane & 63]; }
 // wv_uniform: on the GPU a hint (readfirstlane); here a check that the value really is the same in all lanes
 void emu_not_uniform(int line);

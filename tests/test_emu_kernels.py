@@ -172,6 +172,30 @@ def test_emulated_dfast_parse_matches_oracle(emu, oracle):
                 assert r == len(want) and buf.raw[:r] == want, (len(d), level)
 
 
+def test_emulated_greedy_chunks_match_oracle(emu, oracle):
+    """zsa_greedy_row_chunk (level 5 above 16 KiB: 64 searches per set-up).  Besides ordinary text: a periodic stretch that runs
+    across a block boundary -- the next block opens with a long repcode match, so the positions pending from the last block
+    must enter the table by the rule for long gaps (both ends only), not all of them as a chunk's first search would enter
+    them --, runs of equal bytes (neighbouring positions share rows), literal stretches long enough for the search step to
+    grow, and the three clevels.h tables (minMatch 4 / 5, 16- and 32-entry rows)."""
+    rnd = random.Random(12)
+    text = lambda n, seed: corpus.frames("log", n, 1, seed)[0]
+    unit = rnd.randbytes(24)
+    crossing = text(131072 - 2000, 1) + unit * 170 + text(60000, 2) + unit * 40 + text(80000, 3)      # > 256 KB: minMatch 5
+    mixed = text(30000, 4) + bytes(3000) + rnd.randbytes(2500) + text(20000, 5) + b"ab" * 900 + rnd.randbytes(700) + text(9000, 6)
+    cases = [(crossing, 5), (crossing[:262144], 4), (mixed, 5), (text(131072, 7), 5), (corpus.frames("json", 65536, 1, 8)[0], 5),
+             (text(200000, 9), 5), (text(131072 - 900, 10) + unit * 80 + text(5000, 11), 5)]
+    stat = (ctypes.c_ulonglong * 8).in_dll(emu, "g_zsa_stat")
+    chunks0 = stat[0]
+    for d, level in cases:
+        want = oracle.compress(d, level)
+        cap = zstd_amd.CompressBound(len(d))
+        buf = ctypes.create_string_buffer(cap + 1)
+        r = emu.emu_compress_level(buf, cap, d, len(d), level)
+        assert r == len(want) and buf.raw[:r] == want, (len(d), level)
+    assert stat[0] - chunks0 > 5000        # (the chunk path did the work)
+
+
 def test_emulated_lazy_parse_matches_oracle(emu, oracle):
     """zsa_lazy.h (greedy / lazy / lazy2 with the hash-chain and the row-hash match finders: levels 4..12 where clevels.h
     selects them; level 5 is the reference's default) through the whole frame encoder, cost-based sequence modes and

@@ -571,3 +571,26 @@ def test_level1_chunk_and_general_paths(z, oracle):
                                                  corpus.frames("log", 600000, 1, 9)[0]]
     for level in (1, 2, -1):
         _check_compress(z, oracle, frames, level)
+
+
+def test_chains_of_short_dependent_matches(z, oracle):
+    """Decoder hand-over of global memory between lanes (ZSA_DEP_FENCE = wv_wave_fence): batches in which nearly every one of
+    the 64 sequences is a short match whose source is the output of the match before it (offset < 10, often below the match
+    length), so a missed ordering between a lane's store and the next lane's load would corrupt the output.  Frames from the
+    oracle at levels 1 and 5 decoded on the GPU, and compressed on the GPU byte-identically."""
+    rnd = random.Random(11)
+    frames = []
+    for _ in range(12):
+        d = bytearray(rnd.randbytes(16))
+        while len(d) < 60000:
+            off, ln = rnd.randrange(1, 10), rnd.randrange(4, 12)
+            for _ in range(ln):
+                d.append(d[-off])
+            d.append(rnd.randrange(256))
+        frames.append(bytes(d))
+    for level in (1, 5):
+        comp = [oracle.compress(f, level) for f in frames]
+        assert all(len(c) < len(f) // 2 for c, f in zip(comp, frames))     # (matches dominate)
+        back = z.DecompressBatch(comp, [len(f) for f in frames])
+        assert all(b == f for b, f in zip(back, frames))
+        _check_compress(z, oracle, frames, level)

@@ -9,7 +9,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _run_both(z, torch, frames_c, sizes):
+def _run_both(z, torch, frames_c, sizes, ddict=None):
     from zstd_amd._lib import lib
     n = len(frames_c)
     dev = torch.device("cuda", 0)
@@ -28,7 +28,7 @@ def _run_both(z, torch, frames_c, sizes):
     out_a = torch.zeros(d_total, dtype=torch.uint8, device=dev)
     b = z.DeviceBatch(n)
     b.set_frames(cbuf.data_ptr(), coff, [len(c) for c in frames_c], out_a.data_ptr(), doff, sizes, stream)
-    b.decompress(None, stream)
+    b.decompress(ddict, stream)
     res_a = b.results(stream)
     b.close()
     # (b) the allocation-free one: descriptors and result words are caller-owned device memory
@@ -38,7 +38,7 @@ def _run_both(z, torch, frames_c, sizes):
     res = torch.full((n,), -1, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
     free0 = torch.cuda.mem_get_info()[0]
-    rc = lib.zsa_decompress_frames_noalloc(desc.data_ptr(), res.data_ptr(), n, None, stream)
+    rc = lib.zsa_decompress_frames_noalloc(desc.data_ptr(), res.data_ptr(), n, ddict, stream)
     assert rc == 0, z.ErrorCode(rc - 2 ** 64)
     torch.cuda.synchronize()
     assert torch.cuda.mem_get_info()[0] == free0, "the call changed the amount of free device memory"
@@ -76,3 +76,66 @@ def test_no_alloc_entry_point_matches_batch_entry_point(oracle):
     from zstd_amd._lib import lib
     rc = lib.zsa_decompress_frames_noalloc(1, 1, (1 << 20) + 1, None, None)
     assert z.api.lib.zsa_isError(rc) and str(z.ErrorCode(rc - 2 ** 64)) == "Parameter is out of bound"
+
+
+def test_no_alloc_entry_point_with_a_dictionary(oracle):
+    """the same comparison for frames that name a dictionary (device digest of zsa_createDDict)"""
+    import base64, json, os
+    import torch
+    import zstd_amd as z
+    from zstd_amd import corpus
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "dict_cases.json")))
+    d = base64.b64decode(g["dicts"]["trained_json_8k"]["b64"])
+    frames = corpus.frames("json", 1024, 150, 7) + corpus.frames("json", 9000, 6, 8)
+    ocd = oracle.cdict(d, 1)
+    comp = [oracle.compress_cdict(f, ocd) for f in frames]
+    oracle.free_cdict(ocd)
+    bp = z.NewBulkProcessor(d, 1)
+    res, out, doff = _run_both(z, torch, comp, [len(f) for f in frames], bp.dDict)
+    for i, f in enumerate(frames):
+        assert res[i] == len(f) and out[doff[i]:doff[i] + len(f)].tobytes() == f
+    # without the dictionary the frames are refused ("Dictionary mismatch"), through either entry point alike
+    res2, _, _ = _run_both(z, torch, comp[:3], [len(f) for f in frames[:3]], None)
+    assert all(r >= 2 ** 63 for r in res2)
+
+
+_FIRST_CALL = r"""
+import ctypes, sys
+sys.path.insert(0, %(root)r)
+import torch
+from zstd_amd._lib import lib          # (loads the library; nothing is launched or allocated by it yet)
+frame = bytes.fromhex(%(frame)r)
+want = bytes.fromhex(%(want)r)
+dev = torch.device("cuda", 0)
+c = torch.frombuffer(bytearray(frame), dtype=torch.uint8).to(dev)
+out = torch.zeros(len(want), dtype=torch.uint8, device=dev)
+desc = torch.tensor([[c.data_ptr(), out.data_ptr(), len(frame), len(want)]], dtype=torch.int64, device=dev)
+res = torch.full((1,), -1, dtype=torch.int64, device=dev)
+torch.cuda.synchronize()
+assert lib.zsa_noalloc_prepare() == 0   # the documented warm-up: resolves the workspace address, launches nothing
+rc = lib.zsa_decompress_frames_noalloc(desc.data_ptr(), res.data_ptr(), 1, None, None)
+torch.cuda.synchronize()
+assert rc == 0, rc
+assert int(res.cpu()[0]) == len(want) and bytes(out.cpu().numpy()) == want
+# (the HIP runtime itself sets up the kernel's private-memory arena at a code object's first launch; from then on nothing moves)
+out.zero_(); res.fill_(-1); torch.cuda.synchronize()
+free0 = torch.cuda.mem_get_info()[0]
+rc = lib.zsa_decompress_frames_noalloc(desc.data_ptr(), res.data_ptr(), 1, None, None)
+torch.cuda.synchronize()
+assert rc == 0 and torch.cuda.mem_get_info()[0] == free0
+assert int(res.cpu()[0]) == len(want) and bytes(out.cpu().numpy()) == want
+print("first-call ok")
+"""
+
+
+def test_no_alloc_entry_point_as_the_first_call_of_a_process(oracle):
+    """No zsa_batch, no dictionary and no other launch of the library before it: a fresh process whose first use of the
+    library is zsa_noalloc_prepare + the allocation-free call."""
+    import os, subprocess, sys
+    from zstd_amd import corpus
+    want = corpus.frames("log", 50000, 1, 3)[0]
+    frame = oracle.compress(want, 1)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _FIRST_CALL % {"root": root, "frame": frame.hex(), "want": want.hex()}],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "first-call ok" in r.stdout, r.stdout + r.stderr

@@ -20,7 +20,7 @@
 #include "zsa_common.h"
 
 #ifndef ZSA_DEP_FENCE
-#define ZSA_DEP_FENCE() wv_lds_fence()
+#define ZSA_DEP_FENCE() wv_wave_fence()
 #endif
 
 // ---- packed sequence-table cell: baseValue | nextState<<32 | nbAdditionalBits<<48 | nbBits<<56

@@ -65,6 +65,9 @@ struct ZsaSeqEncScratch { u8 code[3][64]; u16 stBits[3][64]; u8 stNb[3][64]; u32
 // price and repeat them (:206-232), so they are parked in the workgroup's global scratch (ZsaEncScratch::park).
 #define ZSA_FILT_HLOG_MAX 13u     // the chunk path's LDS filter: 4 bits per cell for match tables of up to 1 << 13 cells,
                                   // 2 bits per cell for 1 << 14 (256 KiB level-1 frames)
+#ifndef ZSA_SEQ_HOOK          // test builds (tests/emu) can look at a block's sequences
+#define ZSA_SEQ_HOOK(seq, n) do {} while (0)
+#endif
 struct ZsaEncShared {
     union {
         struct {   // entropy stages
@@ -1485,7 +1488,12 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
                 u32 rep[3] = { S->prevRep[0], S->prevRep[1], S->prevRep[2] };
                 u32 lastLL = 0, nbSeq;
                 if (FAMILY == 1) {   // greedy / lazy / lazy2 (never with a dictionary here): wave-uniform, zsa_lazy.h
+                    // the greedy chunk path's row bitmap lies in `dupBits`, which overlays the last block's FSE tables (parked in
+                    // global scratch from ZSTD_lazy on, never used again below it), not the Huffman table carried from block to block
+                    if (P.strat == 3) for (u32 i = (u32)lane; i < sizeof(S->dupBits) / 4; i += ZSA_WAVE) S->dupBits[i] = 0;
+                    wv_sync();
                     nbSeq = zsa_parse_lazy(LZ, Wn.dictLimit, ip, blockSize, P.strat - 3, rep, W.seq, &lastLL, lane);
+                    ZSA_SEQ_HOOK(W.seq, nbSeq);
                 } else if (FAMILY == 3) {   // ZSTD_dfast (never with a dictionary here): wave-level, zsa_dfast.h
                     // its two cell bitmaps lie in `filt`, which overlays table-construction scratch and the last block's FSE tables
                     // (never used again below ZSTD_lazy), not the Huffman table that is carried from block to block

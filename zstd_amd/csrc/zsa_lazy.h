@@ -36,6 +36,17 @@ ZSA_DEV u32 zsa_lz_count(const u8* pIn, const u8* pMatch, const u8* const pInLim
     return (u32)(pIn - pStart);
 }
 
+// the same, with the first 32 bytes of both sides requested together: most matches end there, after one round trip
+ZSA_DEV u32 zsa_lz_count32(const u8* pIn, const u8* pMatch, const u8* const pInLimit)
+{
+    if (pIn + 32 > pInLimit) return zsa_lz_count(pIn, pMatch, pInLimit);
+    u64 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { a[i] = wv_ldg64(pIn + 8 * i); b[i] = wv_ldg64(pMatch + 8 * i); }
+#pragma unroll
+    for (int i = 0; i < 4; i++) { u64 const d = a[i] ^ b[i]; if (d) return 8u * (u32)i + ((u32)__builtin_ctzll(d) >> 3); }
+    return 32 + zsa_lz_count(pIn + 32, pMatch + 32, pInLimit);
+}
 
 // zstd_compress.c:1916-1927: the hash salt of a fresh context, ZSTD_advanceHashSalt on hashSalt = hashSaltEntropy = 0
 constexpr u64 zsa_bitmix_c(u64 val, u64 len)
@@ -303,6 +314,276 @@ ZSA_DEV u32 zsa_searchMax(ZsaLazyCtx& C, const u8* ip, u64 vip, const ZsaSrcWin&
     return C.useRow ? zsa_row_findBestMatch(C, ip, vip, W, iend, offBasePtr, lane) : zsa_hc_findBestMatch(C, ip, vip, iend, offBasePtr, lane);
 }
 
+// ---------------------------------------------------------------- greedy parse with the row finder, 64 positions at a time
+// (level 5 -- the default of the reference's Compress() -- above 16 KiB; ZSTD_greedy rows of clevels.h with searchLog <= 3)
+//
+// The greedy parse (zstd_lazy.c:1554-1603, depth 0) visits position after position: repcode check at ip + 1, else a search at
+// ip -- which first enters every position below ip into its row, then reads ip's row, then enters ip itself -- and the first
+// of the two that yields 4 bytes makes a sequence.  One chain, and every link of it waits for tables that no cache holds.
+// But the table a search reads is a pure function of the positions BEFORE it: as long as no earlier position of a stretch
+// falls into the row a later one reads, all searches of the stretch can be made against the table as it stood at the
+// stretch's start.  So a CHUNK is 64 consecutive positions, lane k <-> position ip0 + k:
+//   * every lane hashes its position, reads its row's tags (16 or 32 bytes), takes the first nbAttempts slots whose tag agrees
+//     (newest first, from the row's head), reads their cells, drops what lies below the window, and compares 4 bytes of what
+//     is left with its own: the candidates that survive are exactly those that can make a match (a candidate whose first 4
+//     bytes differ is never longer than 3, :1242-1258) -- four memory round trips for 64 searches instead of one chain of 64;
+//   * lanes that share a row with an earlier lane are found by comparing row numbers; the chunk is valid below the first;
+//   * the events are then picked on lane masks in the reference's order (repcode at ip + 1 before the search at ip; the
+//     immediate repcode after every sequence, :1735-1745): M1 / M2 hold the lanes whose 4 bytes equal the 4 bytes offset_1 /
+//     offset_2 behind them, H the lanes whose search finds a match.  Only the winning search is measured (one candidate per
+//     lane, first maximum: zsa_lazy_evaluate), caught up backwards, and stored;
+//   * nothing enters the table while a chunk is scanned; when it is left, the positions that the reference has entered by
+//     then -- everything up to the last search made -- are entered by zsa_row_insert_range, 64 per round trip.
+// What the chunk does not handle is left to the serial loop below: searches that start more than 320 positions behind the
+// last table update (the reference then enters only the two ends of the gap, :896-923), literal runs of 192 bytes and more
+// (the step grows and searches start to skip, :1591-1603), the last 104 bytes of a block, stretches where neighbouring
+// positions share rows (runs of equal bytes), rows of 64 entries and searches of more than 8 attempts.
+struct ZsaGreedyState {   // what the chunk parser takes over from the serial loop and hands back (a copy: the loop's own state stays in registers)
+    u32 ip, anchor, off1, off2, nbSeq, hold, nextToUpdate;
+    ZsaEncShared* S; u32* hashTable; u8* tagTable; const u8* base;
+    u32 hlog, wlog, slog, mls, rowLog, rowHashLog, lowLimit;
+};
+
+// bit i set iff byte i of w equals the byte that `rep` repeats four times
+ZSA_DEV u32 zsa_eq4(u32 w, u32 rep)
+{
+    u32 const x = w ^ rep;
+    u32 t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    t = ~(t | x | 0x7F7F7F7Fu);                          // 0x80 in every byte of x that is zero
+    return (((t >> 7) * 0x00204081u) >> 21) & 0xFu;
+}
+// zstd_lazy.c:1685-1698: bytes in front of the match that agree as well (start > anchor, match > prefixLowest)
+ZSA_DEV u32 zsa_lazy_catchup(const u8* start, const u8* m, const u8* anchor, const u8* prefixLowest)
+{
+    u32 const roomA = (u32)(start - anchor), roomM = (u32)(m - prefixLowest);
+    u32 const maxBack = roomA < roomM ? roomA : roomM;
+    u32 back = 0;
+    if (maxBack > 0 && roomM >= 8) {   // 8 bytes before both in one round trip
+        u64 const d = wv_ldg64(start - 8) ^ wv_ldg64(m - 8);
+        back = d ? ((u32)__builtin_clzll(d) >> 3) : 8;
+        if (back > maxBack) back = maxBack;
+        if (back == 8) while (back < maxBack && wv_ldg8(start - 1 - back) == wv_ldg8(m - 1 - back)) back++;
+    } else {
+        while (back < maxBack && wv_ldg8(start - 1 - back) == wv_ldg8(m - 1 - back)) back++;
+    }
+    return back;
+}
+
+#define ZSA_GREEDY_CAND 8
+ZSA_DEVFN void zsa_greedy_row_chunk(ZsaGreedyState* stp, u64* seqOutIn, u32 iendIdx, u32 prefixLowestIdx)
+{
+    int const lane = wv_lane();
+    ZsaLazyCtx C;
+    C.S = (ZsaEncShared*)wv_uniform64((u64)stp->S);
+    C.hashTable = (u32*)wv_uniform64((u64)stp->hashTable); C.chainTable = nullptr; C.tagTable = (u8*)wv_uniform64((u64)stp->tagTable);
+    C.base = (const u8*)wv_uniform64((u64)stp->base);
+    C.hlog = wv_uniform(stp->hlog); C.clog = 0; C.wlog = wv_uniform(stp->wlog); C.slog = wv_uniform(stp->slog); C.mls = wv_uniform(stp->mls);
+    C.rowLog = wv_uniform(stp->rowLog); C.rowHashLog = wv_uniform(stp->rowHashLog); C.lowLimit = wv_uniform(stp->lowLimit);
+    C.nextToUpdate = wv_uniform(stp->nextToUpdate); C.lazySkipping = 0; C.useRow = true;
+    C.cBase = 0; C.cN = 0; C.cTag = 0; C.cCell = 0; C.cRel = 0;
+    u64* const seqOut = (u64*)wv_uniform64((u64)seqOutIn);
+    iendIdx = wv_uniform(iendIdx); prefixLowestIdx = wv_uniform(prefixLowestIdx);
+    u32 ip = wv_uniform(stp->ip), anchor = wv_uniform(stp->anchor), off1 = wv_uniform(stp->off1), off2 = wv_uniform(stp->off2);
+    u32 nbSeq = wv_uniform(stp->nbSeq), hold = wv_uniform(stp->hold);
+    const u8* const base = C.base;
+    u32 const rowLog = C.rowLog, rowEntries = 1u << rowLog, rowMask = rowEntries - 1u;
+    u32 const entriesMask = rowEntries < 32 ? (1u << rowEntries) - 1u : 0xFFFFFFFFu;
+    u32 const nbAttempts = 1u << (C.slog < rowLog ? C.slog : rowLog);
+    u32 const maxDistance = 1u << C.wlog;
+    const u8* const iend = base + iendIdx;
+
+    for (;;) {   // one chunk per iteration
+        if (ip < hold || ip - C.nextToUpdate > 320 || ip - anchor >= 192 || ip + 64 + 40 > iendIdx) break;
+        u32 const ip0 = ip;
+        ZSA_STAT(0);
+        ZSA_PPROF(C.S, lane, 1);
+        u32 const q = ip0 + (u32)lane;
+        const u8* const pq = base + q;
+        u64 const v = wv_ldg64(pq);
+        u32 const r1 = wv_ldg32(pq - off1), r2 = wv_ldg32(pq - off2);        // (an offset of 0 reads the lane's own bytes: its mask is dropped below)
+        u64 M1 = off1 ? wv_ballot(r1 == (u32)v) : 0, M2 = off2 ? wv_ballot(r2 == (u32)v) : 0;
+        if ((M1 >> 1) & 1ull) {
+            // The repcode at ip0 + 1 hits: no search is made at ip0, so nothing enters the table here -- and what enters it at the
+            // next search depends on how far away that one is (:896-923).  The sequence is stored and the chunk starts over behind it.
+            u32 const start = ip0 + 1;
+            u32 const mlen = zsa_lz_count32(base + start + 4, base + start + 4 - off1, iend) + 4;
+            if (lane == 0) seqOut[nbSeq] = zsa_packseq(start - anchor, mlen - ZSA_MINMATCH, 1);
+            ZSA_STAT(3);
+            nbSeq++;
+            ip = anchor = start + mlen;
+            for (;;) {   // :1735-1745 immediate repcode
+                if (!(((s32)(iendIdx - ip) >= 16) && off2 > 0)) break;
+                u32 const o2 = ip - ip0;
+                bool const hit = o2 < 64 ? ((M2 >> o2) & 1ull) != 0 : wv_ldg32(base + ip) == wv_ldg32(base + ip - off2);
+                if (!hit) break;
+                u32 const ml2 = zsa_lz_count32(base + ip + 4, base + ip + 4 - off2, iend) + 4;
+                { u32 const t = off2; off2 = off1; off1 = t; }
+                { u64 const t = M2; M2 = M1; M1 = t; }
+                if (lane == 0) seqOut[nbSeq] = zsa_packseq(0, ml2 - ZSA_MINMATCH, 1);
+                nbSeq++;
+                ip += ml2; anchor = ip;
+            }
+            continue;
+        }
+        zsa_row_insert_range(C, C.nextToUpdate, ip0, rowMask, lane);   // what the search at ip0 enters first (:1184-1186; no more than 320 positions: all of them)
+        C.nextToUpdate = ip0;
+        ZSA_PPROF(C.S, lane, 8);
+        // ---- set-up: 64 searches against the table as it stands
+        u32 const hash = zsa_hash_salted(v, C.rowHashLog + 8, C.mls, ZSA_FRESH_HASH_SALT);
+        u32 const relRow = (hash >> 8) << rowLog;
+        u32 const tagRep = (hash & 0xFFu) * 0x01010101u;
+        const u8* const tagRow = C.tagTable + relRow;
+        u64 const ta = wv_ldg64(tagRow), tb = wv_ldg64(tagRow + 8);
+        u64 tc = 0, td = 0;
+        if (rowLog == 5) { tc = wv_ldg64(tagRow + 16); td = wv_ldg64(tagRow + 24); }   // (uniform)
+        u32 eq = zsa_eq4((u32)ta, tagRep) | (zsa_eq4((u32)(ta >> 32), tagRep) << 4) | (zsa_eq4((u32)tb, tagRep) << 8) | (zsa_eq4((u32)(tb >> 32), tagRep) << 12);
+        if (rowLog == 5) eq |= (zsa_eq4((u32)tc, tagRep) << 16) | (zsa_eq4((u32)(tc >> 32), tagRep) << 20) | (zsa_eq4((u32)td, tagRep) << 24) | (zsa_eq4((u32)(td >> 32), tagRep) << 28);
+        u32 const head = (u32)ta & 0xFFu & rowMask;
+        eq &= ~1u;                                                           // slot 0 holds the head, never an entry (:1210)
+        u32 rot = head ? (((eq >> head) | (eq << (rowEntries - head))) & entriesMask) : eq;   // newest entry first (:1205-1208)
+        u32 cell[ZSA_GREEDY_CAND];
+        u32 have = 0;
+#pragma unroll
+        for (u32 i = 0; i < ZSA_GREEDY_CAND; i++) cell[i] = 0;
+#pragma unroll
+        for (u32 i = 0; i < ZSA_GREEDY_CAND; i++) {
+            bool const h = rot != 0 && i < nbAttempts;
+            if (!wv_ballot(h)) break;                                        // (uniform: most rows hold one or two entries of a tag)
+            u32 const pos = (head + (h ? (u32)__builtin_ctz(rot) : 0u)) & rowMask;
+            if (h) { cell[i] = wv_ldg_cell(C.hashTable + relRow + pos); have |= 1u << i; rot &= rot - 1u; }
+        }
+        // the list ends before the first index below the window (:1213); then the 4 bytes
+        u32 const lowLimit = (q - C.lowLimit > maxDistance) ? q - maxDistance : C.lowLimit;
+        u32 alive = 0;
+        {   bool on = true;
+#pragma unroll
+            for (u32 i = 0; i < ZSA_GREEDY_CAND; i++) { on = on && ((have >> i) & 1u) && cell[i] >= lowLimit; if (on) alive |= 1u << i; }
+        }
+        u32 first4[ZSA_GREEDY_CAND];
+#pragma unroll
+        for (u32 i = 0; i < ZSA_GREEDY_CAND; i++) first4[i] = 0;
+#pragma unroll
+        for (u32 i = 0; i < ZSA_GREEDY_CAND; i++) {
+            bool const a = ((alive >> i) & 1u) != 0;
+            if (!wv_ballot(a)) break;
+            if (a) first4[i] = wv_ldg32(base + cell[i]);
+        }
+        u32 pm = 0;                                                          // candidates that can make a match
+#pragma unroll
+        for (u32 i = 0; i < ZSA_GREEDY_CAND; i++) if (((alive >> i) & 1u) && first4[i] == (u32)v) pm |= 1u << i;
+        // lanes whose row another lane of the chunk falls into as well, by a bitmap pass over the row numbers (as zsa_parse.h does
+        // for cells: the first lane to reach a row's bit finds it clear, the others find it set and clear it again, which tells the
+        // first one).  Below the second-lowest of them no two lanes share a row.  (row numbers modulo 8192: a false share only
+        // shortens the chunk; the bitmap is all zero between uses)
+        u32 winValid;
+        {   u32 const rowNo = hash >> 8;
+            u32* const dw = &C.S->dupBits[(rowNo >> 5) & 255u];
+            u32 const bit = 1u << (rowNo & 31u);
+            u32 const dprev = wv_atomic_or_lds(dw, bit);
+            bool const late = (dprev & bit) != 0;
+            wv_lds_fence();
+            (void)wv_atomic_and_lds(dw, late ? ~bit : 0xFFFFFFFFu);
+            wv_lds_fence();
+            bool const shares = late | ((*dw & bit) == 0);
+            wv_lds_fence();
+            *dw = 0;
+            wv_lds_fence();
+            u64 const G = wv_ballot(shares);
+            u64 const G2 = G & (G - 1);
+            winValid = G2 ? (u32)__builtin_ctzll(G2) : 64u;
+        }
+        if (winValid < 8) hold = ip0 + 48;                                   // runs of equal bytes: the serial loop takes the next stretch
+        u32 const lim = winValid < 63 ? winValid : 63u;                      // positions [ip0, ip0 + lim) are decided here
+        u64 const H = wv_ballot(pm != 0) & (((u64)1 << lim) - 1u);
+        u32 ntu = ip0;                                                       // first position the reference has not entered yet
+        ZSA_PPROF(C.S, lane, 9);
+        // ---- events
+        for (;;) {
+            u32 const o = ip - ip0;                                          // < lim
+            u32 fr = wv_ff1_64((M1 >> o) >> 1);                              // repcode at (ip + fr) + 1
+            u32 const fh = wv_ff1_64(H >> o);                                // search at ip + fh finds a match
+            if (fr >= lim - o) fr = 0xFFFFFFFFu;
+            if ((fr & fh) == 0xFFFFFFFFu) { ip = ip0 + lim; ntu = ip; break; }   // nothing: every position was searched in vain
+            u32 start, mlen, offBase;
+            if (fr <= fh) {
+                u32 const p = ip + fr;
+                if (fr) ntu = p;                                             // (positions ip .. p - 1 were searched)
+                start = p + 1; offBase = 1;
+                mlen = zsa_lz_count32(base + start + 4, base + start + 4 - off1, iend) + 4;
+            } else {
+                u32 const cur = ip + fh, L = cur - ip0;
+                ntu = cur + 1;
+                u32 const pmL = wv_readlane(pm, (int)L);
+                u32 myIndex = 0, nCand = 0;
+#pragma unroll
+                for (u32 i = 0; i < ZSA_GREEDY_CAND; i++) {
+                    u32 const ci = wv_readlane(cell[i], (int)L);
+                    if ((pmL >> i) & 1u) { if ((u32)lane == nCand) myIndex = ci; nCand++; }
+                }
+                ZSA_PPROF(C.S, lane, 10);
+                // one candidate per lane, each measured in full; the first of the longest wins (zsa_lazy_evaluate).  With a single
+                // candidate the offset is known beforehand, and what follows the measurement -- the new offset's mask, the bytes in
+                // front of the match -- is requested in the same round trip
+                u32 const cand0 = wv_readlane(myIndex, 0);
+                bool const single = nCand == 1;
+                u32 rn = 0; u64 fa = 0, fb = 0;
+                u32 const roomM0 = cand0 - prefixLowestIdx;
+                bool const front = single && cur > anchor && roomM0 >= 8;
+                if (single) rn = wv_ldg32((u32)lane >= L ? pq - (cur - cand0) : pq);
+                if (front) { fa = wv_ldg64(base + cur - 8); fb = wv_ldg64(base + cand0 - 8); }
+                u32 const len = (u32)lane < nCand ? zsa_lz_count32(base + cur, base + myIndex, iend) : 0u;
+                u32 ml = 3, which = 0;
+                for (u32 k = 0; k < nCand; k++) { u32 const l = wv_readlane(len, (int)k); if (l > ml) { ml = l; which = k; } }   // first maximum
+                u32 const off = cur - wv_readlane(myIndex, (int)which), ofb = off + 3;
+                ZSA_PPROF(C.S, lane, 11);
+                if (!single) rn = wv_ldg32((u32)lane >= L ? pq - off : pq);  // (lanes behind the match are not looked at again; the offset may reach below the frame from there)
+                u32 back;
+                if (front) {   // zstd_lazy.c:1685-1698 with the 8 bytes in front of both already here
+                    u32 const roomA = cur - anchor, maxBack = roomA < roomM0 ? roomA : roomM0;
+                    u64 const d = fa ^ fb;
+                    back = d ? ((u32)__builtin_clzll(d) >> 3) : 8;
+                    if (back > maxBack) back = maxBack;
+                    if (back == 8) while (back < maxBack && wv_ldg8(base + cur - 1 - back) == wv_ldg8(base + cand0 - 1 - back)) back++;
+                } else back = zsa_lazy_catchup(base + cur, base + cur - off, base + anchor, base + prefixLowestIdx);
+                start = cur - back; mlen = ml + back; offBase = ofb;
+                off2 = off1; M2 = M1; off1 = off; M1 = wv_ballot(rn == (u32)v);
+            }
+            if (lane == 0) seqOut[nbSeq] = zsa_packseq(start - anchor, mlen - ZSA_MINMATCH, offBase);
+            ZSA_STAT(3);
+            nbSeq++;
+            ip = anchor = start + mlen;
+            // :1735-1745 immediate repcode
+            for (;;) {
+                if (!(((s32)(iendIdx - ip) >= 16) && off2 > 0)) break;
+                u32 const o2 = ip - ip0;
+                bool const hit = o2 < 64 ? ((M2 >> o2) & 1ull) != 0 : wv_ldg32(base + ip) == wv_ldg32(base + ip - off2);
+                if (!hit) break;
+                u32 const ml2 = zsa_lz_count32(base + ip + 4, base + ip + 4 - off2, iend) + 4;
+                { u32 const t = off2; off2 = off1; off1 = t; }
+                { u64 const t = M2; M2 = M1; M1 = t; }
+                if (lane == 0) seqOut[nbSeq] = zsa_packseq(0, ml2 - ZSA_MINMATCH, 1);
+                nbSeq++;
+                ip += ml2; anchor = ip;
+            }
+            if (ip - ip0 >= lim) break;
+        }
+        ZSA_PPROF(C.S, lane, 10);
+        // ---- the positions the reference has entered by now: [ip0, ntu), all below winValid, so each in a row of its own that
+        // nothing has touched since the set-up read its head (zstd_lazy.c:786-791 ZSTD_row_nextIndex + :1224-1230)
+        wv_lds_fence();
+        if ((u32)lane < ntu - ip0) {
+            u32 next = (head - 1u) & rowMask;
+            next += (next == 0) ? rowMask : 0;
+            wv_stg8((u8*)tagRow, next); wv_stg8((u8*)tagRow + next, hash & 0xFFu); wv_stg_cell(C.hashTable + relRow + next, q);
+        }
+        wv_sync();   // the next chunk, and the serial loop, read what this one stored
+        C.nextToUpdate = ntu;
+        ZSA_PPROF(C.S, lane, 7);
+    }
+    stp->ip = ip; stp->anchor = anchor; stp->off1 = off1; stp->off2 = off2; stp->nbSeq = nbSeq; stp->hold = hold;   // (per-lane copies of uniform values)
+    stp->nextToUpdate = C.nextToUpdate;
+}
+
 // depth 0 = greedy, 1 = lazy, 2 = lazy2 (zstd_lazy.c:1493-1757).  Appends packed sequences to seqOut, returns their
 // number; rep[] and *lastLL are updated.  Called by all lanes with uniform arguments; everything it computes is uniform.
 ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcSize, u32 depth, u32 rep[3], u64* seqOut, u32* lastLL, int lane)
@@ -331,7 +612,30 @@ ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcS
     ZsaSrcWin W, R;   // source bytes around ip, and around ip - offset_1
     W.p = R.p = nullptr; W.max8 = W.max4 = R.max8 = R.max4 = 0; W.lo = W.hi = R.lo = R.hi = 0;
 
+    // greedy + row finder: whole chunks of positions where the conditions hold (zsa_greedy_row_chunk), single steps elsewhere
+#ifdef ZSA_NO_GREEDY_CHUNK
+    bool const chunks = false;
+#else
+    bool const chunks = depth == 0 && C.useRow && C.rowLog <= 5 && (C.slog < C.rowLog ? C.slog : C.rowLog) <= 3;
+#endif
+    u32 hold = 0;
     while (ZSA_BEFORE_LIMIT(ip)) {
+        if (chunks && !C.lazySkipping) {
+            u32 const ipIdx = (u32)(ip - C.base);
+            if (ipIdx >= hold && ipIdx - C.nextToUpdate <= 320 && (u32)(ip - anchor) < 192 && ipIdx + 64 + 40 <= (u32)(iend - C.base)) {
+                ZsaGreedyState gs;
+                gs.ip = ipIdx; gs.anchor = (u32)(anchor - C.base); gs.off1 = offset_1; gs.off2 = offset_2; gs.nbSeq = nbSeq; gs.hold = hold;
+                gs.nextToUpdate = C.nextToUpdate; gs.S = C.S; gs.hashTable = C.hashTable; gs.tagTable = C.tagTable; gs.base = C.base;
+                gs.hlog = C.hlog; gs.wlog = C.wlog; gs.slog = C.slog; gs.mls = C.mls; gs.rowLog = C.rowLog; gs.rowHashLog = C.rowHashLog; gs.lowLimit = C.lowLimit;
+                zsa_greedy_row_chunk(&gs, seqOut, (u32)(iend - C.base), dictLimit);
+                bool const moved = wv_uniform(gs.ip) != ipIdx;
+                ip = C.base + wv_uniform(gs.ip); anchor = C.base + wv_uniform(gs.anchor);
+                offset_1 = wv_uniform(gs.off1); offset_2 = wv_uniform(gs.off2); nbSeq = wv_uniform(gs.nbSeq); hold = wv_uniform(gs.hold);
+                C.nextToUpdate = wv_uniform(gs.nextToUpdate);
+                C.cN = 0; W.p = nullptr; R.p = nullptr;
+                if (moved) continue;
+            }
+        }
         u32 matchLength = 0;
         u32 offBase = 1;   // REPCODE1_TO_OFFBASE
         const u8* start = ip + 1;
@@ -392,22 +696,13 @@ ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcS
             if (offBase > 3) {   // :1685-1698 catch up
                 u32 const off = offBase - 3;
                 const u8* const m = start - off;
-                u32 const roomA = (u32)(start - anchor), roomM = (u32)(m - prefixLowest);   // start > anchor & match > prefixLowest
-                u32 const maxBack = roomA < roomM ? roomA : roomM;
-                u32 back = 0;
-                if (maxBack > 0 && roomM >= 8) {   // 8 bytes before both in one round trip
-                    u64 const d = wv_ldg64(start - 8) ^ wv_ldg64(m - 8);
-                    back = d ? ((u32)__builtin_clzll(d) >> 3) : 8;
-                    if (back > maxBack) back = maxBack;
-                    if (back == 8) while (back < maxBack && wv_ldg8(start - 1 - back) == wv_ldg8(m - 1 - back)) back++;
-                } else {
-                    while (back < maxBack && wv_ldg8(start - 1 - back) == wv_ldg8(m - 1 - back)) back++;
-                }
+                u32 const back = zsa_lazy_catchup(start, m, anchor, prefixLowest);
                 start -= back; matchLength += back;
                 offset_2 = offset_1; offset_1 = off;
             }
         }
         // :1700-1704 _storeSequence
+        ZSA_STAT(5);
         if (lane == 0) seqOut[nbSeq] = zsa_packseq((u32)(start - anchor), matchLength - ZSA_MINMATCH, offBase);
         nbSeq++;
         anchor = ip = start + matchLength;

@@ -22,6 +22,11 @@ ZSA_DEV void wv_sync() { __syncthreads(); }
 // visible to another lane's later LDS read needs no s_barrier and no wait on outstanding global loads -- only a
 // compiler-level ordering point.
 ZSA_DEV void wv_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+// The same ordering point for GLOBAL memory handed from lane to lane inside one wave (a lane's earlier stores, flat or
+// address-space-1, against another lane's later loads of the same bytes: the decoder's dependent matches, the parsers'
+// match tables).  Sound for a single wave under the AMDGPU memory model: a wave's memory instructions are issued in program
+// order and a wavefront-scope fence keeps the compiler from moving them across it; nothing here synchronises two waves.
+ZSA_DEV void wv_wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 // value of `v` in lane `srcLane`; srcLane must be wave-uniform
 ZSA_DEV unsigned wv_readlane(unsigned v, int srcLane) { return (unsigned)__builtin_amdgcn_readlane((int)v, srcLane); }
 // Tells the compiler that `v` holds the same value in every lane (it cannot always prove it: a value that once passed through
