@@ -80,8 +80,8 @@ size_t zsa_decompress_batch(const void* const* src, const size_t* srcSize, void*
  *    call site passes (zstd.go:96-101) -- else "Destination buffer is too small", even where the frame would have fit.
  *    The HOST-memory entry points (sections 1 and 2) take any capacity, as ZSTD_compress does: the frame is produced in a
  *    bound-sized device slot and handed over when it fits the caller's buffer, else "Destination buffer is too small".
- *    Frames whose sizes are linked on the device (zsa_batch_link_src_sizes) are sized for match tables of up to 5 MiB;
- *    a frame that needs more (levels 7 and up on inputs above 256 KB) gets "Unsupported parameter" in its result word.
+ *    Frames whose sizes are linked on the device (zsa_batch_link_src_sizes) are sized for match tables of up to 8 MiB;
+ *    a frame that needs more (levels 9 and up on inputs above 256 KB) gets "Unsupported parameter" in its result word.
  *    A compress launch whose workspace does not fit half of the device's free memory keeps fewer frames in flight, and an
  *    allocation that is still refused is tried once more at half that before "Allocation error" is returned.
  * ------------------------------------------------------------------------------------------------------- */

@@ -102,7 +102,7 @@ extern "C" void* emu_last_tables() { return g_emu_ht; }   // the match tables as
 extern "C" size_t emu_compress_level(void* dst, size_t cap, const void* src, size_t n, int level)
 {
     static ZsaEncShared S;
-    static u32* ht = (u32*)malloc((size_t)5 << 20);
+    static u32* ht = (u32*)malloc((size_t)9 << 20);
     g_emu_ht = ht;
     static u64* seq = (u64*)malloc(8 * (32768 + 64));
     static u8* lit = (u8*)malloc(ZSA_BLOCKSIZE_MAX + 128);
@@ -111,7 +111,7 @@ extern "C" size_t emu_compress_level(void* dst, size_t cap, const void* src, siz
     static const u8 empty[16] = {0};
     ZsaCParams cp;
     if (zsa_resolveCParams(&cp, level, n, 0, zsa_cpm_noAttachDict)
-        || ((size_t)4 << cp.hlog) + zsa_auxTableBytes(cp.strat, cp.wlog, cp.hlog, cp.clog) > ((size_t)5 << 20)) return (size_t)ZSA_ERR(ZSA_parameter_unsupported);
+        || ((size_t)4 << cp.hlog) + zsa_auxTableBytes(cp.strat, cp.wlog, cp.hlog, cp.clog) > ((size_t)9 << 20)) return (size_t)ZSA_ERR(ZSA_parameter_unsupported);
     EncArgs A = { &S, ht, { cp.wlog, cp.hlog, cp.mml, cp.tlen, cp.clog, cp.strat, cp.slog }, n ? (const u8*)src : empty + 8, n, (u8*)dst, cap, { seq, lit, tmp, park }, nullptr, 0, 0 };
     emu_run_wave(enc_entry, &A);
     return (size_t)A.result;

@@ -1410,7 +1410,7 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
     int const literalsDisabled = (P.strat == 1) && (P.tlen > 0);   // zstd_compress_internal.h:605-618
     u32 const maxDist = 1u << P.wlog;
     ZsaLazyCtx LZ;   // greedy / lazy / lazy2 (zsa_lazy.h): match-finder state that lives across the blocks of the frame
-    LZ.S = S; LZ.hashTable = hashTable; LZ.chainTable = hashTable + (1u << P.hlog); LZ.tagTable = (u8*)(hashTable + (1u << P.hlog));
+    LZ.S = S; LZ.hashTable = hashTable; LZ.chainTable = hashTable + (1u << P.hlog);
     LZ.base = Wn.base; LZ.hlog = P.hlog; LZ.clog = P.clog; LZ.wlog = P.wlog; LZ.slog = P.slog;
     LZ.mls = P.mml < 4 ? 4 : (P.mml > 6 ? 6 : P.mml);
     LZ.rowLog = P.slog < 4 ? 4 : (P.slog > 6 ? 6 : P.slog);

@@ -3,8 +3,9 @@
 // zstd_compress.c:236-252 picks).  These are levels 5..12 where clevels.h has a greedy/lazy/lazy2 row -- level 5 is the
 // default of the reference's Compress() (zstd.go:23,90-92).
 //
-// Tables, all in the workgroup's global scratch: hashTable (1 << hashLog cells), then either the chain table
-// (1 << chainLog cells) or the row finder's tag table (1 << hashLog bytes; byte 0 of every row is the row's head).
+// Tables, all in the workgroup's global scratch.  Hash chain: hashTable (1 << hashLog cells), then the chain table (1 << chainLog
+// cells).  Row finder: one RECORD per row at hashTable, 8 bytes per entry -- the row's tag bytes (byte 0 of every row is the
+// row's head) followed by its cells -- so that the tags and the cells of a row share a 128-byte line (zsa_row_tags / zsa_row_cells).
 //
 // The parser runs in wave-uniform control flow: every lane follows the same chain with the same values (loads of one
 // address by all lanes are one transaction) and lane 0 alone stores, so that the one step with real parallelism can use
@@ -69,7 +70,7 @@ ZSA_DEV u32 zsa_hash_salted(u64 v, u32 hBits, u32 mls, u64 salt)
 
 struct ZsaLazyCtx {
     ZsaEncShared* S;         // phase accounting only (ZSA_PARSE_PROF builds)
-    u32* hashTable; u32* chainTable; u8* tagTable;
+    u32* hashTable; u32* chainTable;
     const u8* base;
     u32 hlog, clog, wlog, slog, mls, rowLog, rowHashLog;
     u32 lowLimit;            // window.lowLimit (no dictionary: loadedDictEnd == 0)
@@ -86,6 +87,10 @@ struct ZsaLazyCtx {
 
 // 16 source bytes at `p`, kept in registers: literal runs are searched position after position, and the bytes a position
 // needs (8 at ip for the hash, 4 at ip+1-offset for the repcode check) mostly lie in what the previous position loaded.
+// the record of the row whose first entry has number relRow (= row number << rowLog): tags, then cells
+ZSA_DEV u8* zsa_row_tags(const ZsaLazyCtx& C, u32 relRow) { return (u8*)C.hashTable + ((size_t)relRow << 3); }
+ZSA_DEV u32* zsa_row_cells(const ZsaLazyCtx& C, u32 relRow) { return (u32*)(zsa_row_tags(C, relRow) + ((size_t)1 << C.rowLog)); }
+
 struct ZsaSrcWin { const u8* p; u32 max8, max4; u64 lo, hi; };
 ZSA_DEV void zsa_win_fill(ZsaSrcWin& W, const u8* p, const u8* iend)
 {
@@ -191,10 +196,10 @@ ZSA_DEV u32 zsa_hc_findBestMatch(ZsaLazyCtx& C, const u8* ip, u64 vip, const u8*
 // zstd_lazy.c:786-791 ZSTD_row_nextIndex + :1224-1230: one position enters its row (uniform; lane 0 stores)
 ZSA_DEV void zsa_row_put(ZsaLazyCtx& C, u32 relRow, u32 tag, u32 idx, u32 rowMask, u32 head, int lane)
 {
-    u8* const tagRow = C.tagTable + relRow;
+    u8* const tagRow = zsa_row_tags(C, relRow);
     u32 next = (head - 1u) & rowMask;
     next += (next == 0) ? rowMask : 0;
-    if (lane == 0) { wv_stg8(tagRow, next); wv_stg8(tagRow + next, tag); wv_stg_cell(C.hashTable + relRow + next, idx); }
+    if (lane == 0) { wv_stg8(tagRow, next); wv_stg8(tagRow + next, tag); wv_stg_cell(zsa_row_cells(C, relRow) + next, idx); }
     if (C.cRel == relRow && ((u32)lane >> C.rowLog) < C.cN) {   // the cached copies of this row
         if (((u32)lane & rowMask) == next) { C.cTag = tag; C.cCell = idx; }
         if (((u32)lane & rowMask) == 0) C.cTag = next;
@@ -215,7 +220,7 @@ ZSA_DEV void zsa_row_insert_range(ZsaLazyCtx& C, u32 from, u32 to, u32 rowMask, 
         u32 const pos = b + (act ? (u32)lane : 0u);
         u32 const hash = zsa_hash_salted(wv_ldg64(C.base + pos), C.rowHashLog + 8, C.mls, ZSA_FRESH_HASH_SALT);
         u32 const relRow = (hash >> 8) << C.rowLog;
-        u8* const tagRow = C.tagTable + relRow;
+        u8* const tagRow = zsa_row_tags(C, relRow);
         u32 const head0 = wv_ldg8(tagRow) & rowMask;
         u32 rank = 0, count = 0;   // positions of this step in my row: before me / in total
         for (u32 s2 = 0; s2 < n; s2++) {
@@ -225,7 +230,7 @@ ZSA_DEV void zsa_row_insert_range(ZsaLazyCtx& C, u32 from, u32 to, u32 rowMask, 
         }
         u32 const c0 = (head0 ? head0 : 1u) - 1u;                       // head 0 (fresh row) steps to rowMask like head 1
         u32 const slot = ((c0 + 5u * rowMask - (rank + 1u)) % rowMask) + 1u;   // rank + 1 <= 64 <= 5 * rowMask
-        if (act && (count - 1u - rank) < rowMask) { wv_stg8(tagRow + slot, hash & 0xFF); wv_stg_cell(C.hashTable + relRow + slot, pos); }
+        if (act && (count - 1u - rank) < rowMask) { wv_stg8(tagRow + slot, hash & 0xFF); wv_stg_cell(zsa_row_cells(C, relRow) + slot, pos); }
         if (act && rank == count - 1u) wv_stg8(tagRow, slot);
         wv_sync();   // the next step, and the search that follows, read what this one stored
     }
@@ -272,8 +277,8 @@ ZSA_DEV u32 zsa_row_findBestMatch(ZsaLazyCtx& C, const u8* ip, u64 vip, const Zs
         u64 const vj = j == 0 ? vip : zsa_win_at(W, known ? dj : 0u);
         u32 const hj = zsa_hash_salted(vj, C.rowHashLog + 8, C.mls, ZSA_FRESH_HASH_SALT);
         u32 const relj = known ? ((hj >> 8) << C.rowLog) : relRow;
-        C.cTag = wv_ldg8(C.tagTable + relj + ((u32)lane & rowMask));
-        C.cCell = wv_ldg_cell(C.hashTable + relj + ((u32)lane & rowMask));
+        C.cTag = wv_ldg8(zsa_row_tags(C, relj) + ((u32)lane & rowMask));
+        C.cCell = wv_ldg_cell(zsa_row_cells(C, relj) + ((u32)lane & rowMask));
         C.cRel = relj;
         C.cBase = curr;
         u32 const groups = (u32)ZSA_WAVE >> C.rowLog;
@@ -340,7 +345,7 @@ ZSA_DEV u32 zsa_searchMax(ZsaLazyCtx& C, const u8* ip, u64 vip, const ZsaSrcWin&
 // positions share rows (runs of equal bytes), rows of 64 entries and searches of more than 8 attempts.
 struct ZsaGreedyState {   // what the chunk parser takes over from the serial loop and hands back (a copy: the loop's own state stays in registers)
     u32 ip, anchor, off1, off2, nbSeq, hold, nextToUpdate;
-    ZsaEncShared* S; u32* hashTable; u8* tagTable; const u8* base;
+    ZsaEncShared* S; u32* hashTable; const u8* base;
     u32 hlog, wlog, slog, mls, rowLog, rowHashLog, lowLimit;
 };
 
@@ -369,13 +374,18 @@ ZSA_DEV u32 zsa_lazy_catchup(const u8* start, const u8* m, const u8* anchor, con
     return back;
 }
 
+// index of the lowest set bit, 0xFFFFFFFF for zero
+ZSA_DEV u32 zsa_first_bit64(u64 x) { return x ? (u32)__builtin_ctzll(x) : 0xFFFFFFFFu; }
 #define ZSA_GREEDY_CAND 8
+#ifndef ZSA_GREEDY_W0
+#define ZSA_GREEDY_W0 32u
+#endif
 ZSA_DEVFN void zsa_greedy_row_chunk(ZsaGreedyState* stp, u64* seqOutIn, u32 iendIdx, u32 prefixLowestIdx)
 {
     int const lane = wv_lane();
     ZsaLazyCtx C;
     C.S = (ZsaEncShared*)wv_uniform64((u64)stp->S);
-    C.hashTable = (u32*)wv_uniform64((u64)stp->hashTable); C.chainTable = nullptr; C.tagTable = (u8*)wv_uniform64((u64)stp->tagTable);
+    C.hashTable = (u32*)wv_uniform64((u64)stp->hashTable); C.chainTable = nullptr;
     C.base = (const u8*)wv_uniform64((u64)stp->base);
     C.hlog = wv_uniform(stp->hlog); C.clog = 0; C.wlog = wv_uniform(stp->wlog); C.slog = wv_uniform(stp->slog); C.mls = wv_uniform(stp->mls);
     C.rowLog = wv_uniform(stp->rowLog); C.rowHashLog = wv_uniform(stp->rowHashLog); C.lowLimit = wv_uniform(stp->lowLimit);
@@ -391,6 +401,10 @@ ZSA_DEVFN void zsa_greedy_row_chunk(ZsaGreedyState* stp, u64* seqOutIn, u32 iend
     u32 const nbAttempts = 1u << (C.slog < rowLog ? C.slog : rowLog);
     u32 const maxDistance = 1u << C.wlog;
     const u8* const iend = base + iendIdx;
+    // A chunk searches as many positions as the search is likely to last: ZSA_GREEDY_W0 behind a sequence, twice as many every
+    // time nothing is found (every searched position costs three scattered table lines, and the tables of the frames in flight
+    // are far larger than any cache: 64-wide chunks spent four fifths of that traffic on positions that a match then skipped)
+    u32 width = ZSA_GREEDY_W0;
 
     for (;;) {   // one chunk per iteration
         if (ip < hold || ip - C.nextToUpdate > 320 || ip - anchor >= 192 || ip + 64 + 40 > iendIdx) break;
@@ -423,6 +437,7 @@ ZSA_DEVFN void zsa_greedy_row_chunk(ZsaGreedyState* stp, u64* seqOutIn, u32 iend
                 nbSeq++;
                 ip += ml2; anchor = ip;
             }
+            width = ZSA_GREEDY_W0;
             continue;
         }
         zsa_row_insert_range(C, C.nextToUpdate, ip0, rowMask, lane);   // what the search at ip0 enters first (:1184-1186; no more than 320 positions: all of them)
@@ -432,14 +447,19 @@ ZSA_DEVFN void zsa_greedy_row_chunk(ZsaGreedyState* stp, u64* seqOutIn, u32 iend
         u32 const hash = zsa_hash_salted(v, C.rowHashLog + 8, C.mls, ZSA_FRESH_HASH_SALT);
         u32 const relRow = (hash >> 8) << rowLog;
         u32 const tagRep = (hash & 0xFFu) * 0x01010101u;
-        const u8* const tagRow = C.tagTable + relRow;
-        u64 const ta = wv_ldg64(tagRow), tb = wv_ldg64(tagRow + 8);
-        u64 tc = 0, td = 0;
-        if (rowLog == 5) { tc = wv_ldg64(tagRow + 16); td = wv_ldg64(tagRow + 24); }   // (uniform)
+        const u8* const tagRow = zsa_row_tags(C, relRow);
+        const u32* const cellRow = zsa_row_cells(C, relRow);
+        bool const searched = (u32)lane < width;
+        u64 ta = 0, tb = 0, tc = 0, td = 0;
+        if (searched) {
+            ta = wv_ldg64(tagRow); tb = wv_ldg64(tagRow + 8);
+            if (rowLog == 5) { tc = wv_ldg64(tagRow + 16); td = wv_ldg64(tagRow + 24); }   // (uniform)
+        }
         u32 eq = zsa_eq4((u32)ta, tagRep) | (zsa_eq4((u32)(ta >> 32), tagRep) << 4) | (zsa_eq4((u32)tb, tagRep) << 8) | (zsa_eq4((u32)(tb >> 32), tagRep) << 12);
         if (rowLog == 5) eq |= (zsa_eq4((u32)tc, tagRep) << 16) | (zsa_eq4((u32)(tc >> 32), tagRep) << 20) | (zsa_eq4((u32)td, tagRep) << 24) | (zsa_eq4((u32)(td >> 32), tagRep) << 28);
         u32 const head = (u32)ta & 0xFFu & rowMask;
         eq &= ~1u;                                                           // slot 0 holds the head, never an entry (:1210)
+        if (!searched) eq = 0;
         u32 rot = head ? (((eq >> head) | (eq << (rowEntries - head))) & entriesMask) : eq;   // newest entry first (:1205-1208)
         u32 cell[ZSA_GREEDY_CAND];
         u32 have = 0;
@@ -450,7 +470,7 @@ ZSA_DEVFN void zsa_greedy_row_chunk(ZsaGreedyState* stp, u64* seqOutIn, u32 iend
             bool const h = rot != 0 && i < nbAttempts;
             if (!wv_ballot(h)) break;                                        // (uniform: most rows hold one or two entries of a tag)
             u32 const pos = (head + (h ? (u32)__builtin_ctz(rot) : 0u)) & rowMask;
-            if (h) { cell[i] = wv_ldg_cell(C.hashTable + relRow + pos); have |= 1u << i; rot &= rot - 1u; }
+            if (h) { cell[i] = wv_ldg_cell(cellRow + pos); have |= 1u << i; rot &= rot - 1u; }
         }
         // the list ends before the first index below the window (:1213); then the 4 bytes
         u32 const lowLimit = (q - C.lowLimit > maxDistance) ? q - maxDistance : C.lowLimit;
@@ -479,31 +499,32 @@ ZSA_DEVFN void zsa_greedy_row_chunk(ZsaGreedyState* stp, u64* seqOutIn, u32 iend
         {   u32 const rowNo = hash >> 8;
             u32* const dw = &C.S->dupBits[(rowNo >> 5) & 255u];
             u32 const bit = 1u << (rowNo & 31u);
-            u32 const dprev = wv_atomic_or_lds(dw, bit);
+            u32 const dprev = searched ? wv_atomic_or_lds(dw, bit) : 0u;
             bool const late = (dprev & bit) != 0;
             wv_lds_fence();
-            (void)wv_atomic_and_lds(dw, late ? ~bit : 0xFFFFFFFFu);
+            if (searched) (void)wv_atomic_and_lds(dw, late ? ~bit : 0xFFFFFFFFu);
             wv_lds_fence();
-            bool const shares = late | ((*dw & bit) == 0);
+            bool const shares = searched && (late | ((*dw & bit) == 0));
             wv_lds_fence();
-            *dw = 0;
+            if (searched) *dw = 0;
             wv_lds_fence();
             u64 const G = wv_ballot(shares);
             u64 const G2 = G & (G - 1);
             winValid = G2 ? (u32)__builtin_ctzll(G2) : 64u;
         }
-        if (winValid < 8) hold = ip0 + 48;                                   // runs of equal bytes: the serial loop takes the next stretch
-        u32 const lim = winValid < 63 ? winValid : 63u;                      // positions [ip0, ip0 + lim) are decided here
+        if (winValid < 4) hold = ip0 + 48;                                   // runs of equal bytes: the serial loop takes the next stretch
+        u32 lim = winValid < 63 ? winValid : 63u;                            // positions [ip0, ip0 + lim) are decided here
+        if (lim > width) lim = width;
         u64 const H = wv_ballot(pm != 0) & (((u64)1 << lim) - 1u);
         u32 ntu = ip0;                                                       // first position the reference has not entered yet
         ZSA_PPROF(C.S, lane, 9);
         // ---- events
         for (;;) {
             u32 const o = ip - ip0;                                          // < lim
-            u32 fr = wv_ff1_64((M1 >> o) >> 1);                              // repcode at (ip + fr) + 1
-            u32 const fh = wv_ff1_64(H >> o);                                // search at ip + fh finds a match
+            u32 fr = zsa_first_bit64((M1 >> o) >> 1);                              // repcode at (ip + fr) + 1
+            u32 const fh = zsa_first_bit64(H >> o);                                // search at ip + fh finds a match
             if (fr >= lim - o) fr = 0xFFFFFFFFu;
-            if ((fr & fh) == 0xFFFFFFFFu) { ip = ip0 + lim; ntu = ip; break; }   // nothing: every position was searched in vain
+            if ((fr & fh) == 0xFFFFFFFFu) { ip = ip0 + lim; ntu = ip; width = width < 32 ? width * 2 : 64u; break; }   // nothing: every position was searched in vain
             u32 start, mlen, offBase;
             if (fr <= fh) {
                 u32 const p = ip + fr;
@@ -552,6 +573,7 @@ ZSA_DEVFN void zsa_greedy_row_chunk(ZsaGreedyState* stp, u64* seqOutIn, u32 iend
             ZSA_STAT(3);
             nbSeq++;
             ip = anchor = start + mlen;
+            width = ZSA_GREEDY_W0;
             // :1735-1745 immediate repcode
             for (;;) {
                 if (!(((s32)(iendIdx - ip) >= 16) && off2 > 0)) break;
@@ -574,7 +596,7 @@ ZSA_DEVFN void zsa_greedy_row_chunk(ZsaGreedyState* stp, u64* seqOutIn, u32 iend
         if ((u32)lane < ntu - ip0) {
             u32 next = (head - 1u) & rowMask;
             next += (next == 0) ? rowMask : 0;
-            wv_stg8((u8*)tagRow, next); wv_stg8((u8*)tagRow + next, hash & 0xFFu); wv_stg_cell(C.hashTable + relRow + next, q);
+            wv_stg8((u8*)tagRow, next); wv_stg8((u8*)tagRow + next, hash & 0xFFu); wv_stg_cell((u32*)cellRow + next, q);
         }
         wv_sync();   // the next chunk, and the serial loop, read what this one stored
         C.nextToUpdate = ntu;
@@ -625,7 +647,7 @@ ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcS
             if (ipIdx >= hold && ipIdx - C.nextToUpdate <= 320 && (u32)(ip - anchor) < 192 && ipIdx + 64 + 40 <= (u32)(iend - C.base)) {
                 ZsaGreedyState gs;
                 gs.ip = ipIdx; gs.anchor = (u32)(anchor - C.base); gs.off1 = offset_1; gs.off2 = offset_2; gs.nbSeq = nbSeq; gs.hold = hold;
-                gs.nextToUpdate = C.nextToUpdate; gs.S = C.S; gs.hashTable = C.hashTable; gs.tagTable = C.tagTable; gs.base = C.base;
+                gs.nextToUpdate = C.nextToUpdate; gs.S = C.S; gs.hashTable = C.hashTable; gs.base = C.base;
                 gs.hlog = C.hlog; gs.wlog = C.wlog; gs.slog = C.slog; gs.mls = C.mls; gs.rowLog = C.rowLog; gs.rowHashLog = C.rowHashLog; gs.lowLimit = C.lowLimit;
                 zsa_greedy_row_chunk(&gs, seqOut, (u32)(iend - C.base), dictLimit);
                 bool const moved = wv_uniform(gs.ip) != ipIdx;

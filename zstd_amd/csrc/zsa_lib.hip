@@ -27,13 +27,13 @@
 #define ZSA_ENC_WAVES 4       // waves per SIMD the compress kernel is register-budgeted for (16 workgroups per CU)
 #endif
 #ifndef ZSA_HT_BYTES
-#define ZSA_HT_BYTES   ((size_t)48 << 20)                    // match table(s) of the frame in flight: 4 << hashLog bytes, plus
-                                                            // 4 << chainLog for ZSTD_dfast (level 4 at > 256 KB: 1 MiB + 1 MiB), the
-                                                            // hash chain or the row finder's tags for greedy/lazy/lazy2 (levels 7-8
-                                                            // at > 256 KB: 4 MiB + 1 MiB; level 12 at >= 4 MiB: 32 MiB + 8 MiB).  A
-                                                            // launch is sized to what its frames need, not to this ceiling
+#define ZSA_HT_BYTES   ((size_t)64 << 20)                    // match table(s) of the frame in flight: 4 << hashLog bytes, plus
+                                                            // 4 << chainLog for ZSTD_dfast (level 4 at > 256 KB: 1 MiB + 1 MiB) or the
+                                                            // hash chain; the row finder's records for greedy/lazy/lazy2 take
+                                                            // 8 << hashLog (levels 7-8 at > 256 KB: 8 MiB; level 12 at >= 4 MiB:
+                                                            // 64 MiB).  A launch is sized to what its frames need, not to this ceiling
 #endif
-#define ZSA_HT_BYTES_UNSIZED ((size_t)5 << 20)               // ... when the frames' sizes are known on the device only
+#define ZSA_HT_BYTES_UNSIZED ((size_t)8 << 20)               // ... when the frames' sizes are known on the device only
 #define ZSA_PARK_BYTES ((3 * sizeof(ZsaFseCT) + 255) / 256 * 256)   // sequence tables of the last compressed block (ZSTD_lazy and up)
 // Compression workspace of one resident workgroup, sized from the launch: `blockCap` = largest block of the batch (<= 128 KiB),
 // `htBytes` = largest match-table footprint any of its frames needs.  [seq | lit | tmp | park | tables]

@@ -39,12 +39,15 @@ ZSA_HD ZsaCParams zsa_levelRow(u32 tableID, u32 row)
 // zstd_compress.c:223-252: greedy/lazy/lazy2 use the row-hash match finder when windowLog > 14 (a SIMD build, as the
 // reference's x86-64 cgo build is), else the hash chain
 ZSA_HD bool zsa_useRowFinder(u32 strat, u32 wlog) { return strat >= 3 && strat <= 5 && wlog > 14; }
-// bytes of the table that follows the hash table in a frame's scratch: ZSTD_dfast's short-hash table, the hash chain, or
-// the row finder's tags (zstd_compress.c:1938-1996)
+// bytes of what follows the first 4 << hashLog bytes of a frame's table scratch: ZSTD_dfast's short-hash table, the hash chain,
+// or -- row finder -- the rest of the row records.  The row finder's table is laid out in RECORDS of 8 bytes per entry, one per
+// row: the row's tag bytes (byte 0 = the head) followed by its cells, so that a search finds a row's tags and cells in the same
+// 128-byte line (libzstd keeps two arrays, zstd_compress.c:1938-1996; the layout is private to the match finder and does not
+// show in its results).  8 << hashLog bytes in all.
 ZSA_HD u32 zsa_auxTableBytes(u32 strat, u32 wlog, u32 hlog, u32 clog)
 {
     if (strat < 2) return 0;
-    if (zsa_useRowFinder(strat, wlog)) return 1u << hlog;
+    if (zsa_useRowFinder(strat, wlog)) return 4u << hlog;
     return 4u << clog;
 }
 // zstd_compress.c:1427-1555 ZSTD_dictAndWindowLog + ZSTD_adjustCParams_internal (strategies below btlazy2: cycleLog == chainLog;
