@@ -61,6 +61,9 @@ size_t zsa_decompress_usingDDict(void* dst, size_t dstCapacity, const void* src,
  *    Batches of 8 MiB and more are staged by helper threads that live for the call (ZSTD_AMD_COPY_THREADS,
  *    default 8, 1 = none; they copy between the caller's buffers and pinned memory and make no HIP calls) and run as up
  *    to four sub-batches on streams of their own, so that upload, kernel and download overlap.
+ *    ZSTD_AMD_DEVICES=<n|all> (default 1: the calling thread's current device only) spreads a batch of 64 MiB and more that
+ *    uses no dictionary over n GPUs -- contiguous shares of about equal bytes, one device-bound worker thread each; the
+ *    reference's callers reach the same by fanning out over goroutines (zstd_stream_test.go:149-169).
  * ------------------------------------------------------------------------------------------------------- */
 size_t zsa_compress_batch(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCapacity,
                           size_t* outSize, size_t nFrames, int compressionLevel, const zsa_CDict* cdict /* or NULL */);

@@ -6,6 +6,8 @@
 #include <string.h>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -1031,12 +1033,97 @@ static size_t zsa_run_host_batch(bool compress, const void* const* src, const si
     return firstError;
 }
 
+// ---- one host batch over several GPUs.  The reference's callers use a whole node by fanning payloads out over goroutines
+// (zstd_stream_test.go:149-169); a process that hands ONE batch to this library gets the same from ZSTD_AMD_DEVICES=<n|all>:
+// a large batch without a dictionary (dictionary digests live on one device) is cut into contiguous shares of about equal
+// bytes, one per device, each run by a worker thread that stays bound to its device and keeps its staging from call to call.
+// Default 1: the calling thread's current device only.
+struct ZsaDevWorker {
+    std::thread th; std::mutex m; std::condition_variable cv;
+    int device = 0; bool busy = false, quit = false;
+    std::function<void()> job;
+};
+static std::mutex g_devMutex;                      // one multi-device batch at a time (the workers are shared)
+static std::vector<ZsaDevWorker*> g_devWorkers;
+static unsigned zsa_batch_devices()
+{
+    static unsigned const conf = [] {
+        const char* e = getenv("ZSTD_AMD_DEVICES");
+        if (!e) return 1u;
+        int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+        if (strcmp(e, "all") == 0) return (unsigned)(n > 0 ? n : 1);
+        int const v = atoi(e);
+        // (ZSTD_AMD_DEVICE_ALIAS=1, a test knob: the shares all run on the current device, so that the split can be exercised on a one-GPU box)
+        if (getenv("ZSTD_AMD_DEVICE_ALIAS")) return (unsigned)(v < 1 ? 1 : (v > 8 ? 8 : v));
+        return (unsigned)(v < 1 ? 1 : (v > n ? (n > 0 ? n : 1) : v));
+    }();
+    return conf;
+}
+static void zsa_dev_worker_main(ZsaDevWorker* w)
+{
+    if (hipSetDevice(w->device) != hipSuccess) (void)hipGetLastError();
+    std::unique_lock<std::mutex> lk(w->m);
+    for (;;) {
+        w->cv.wait(lk, [&] { return w->busy || w->quit; });
+        if (w->quit) break;
+        lk.unlock(); w->job(); lk.lock();
+        w->busy = false;
+        w->cv.notify_all();
+    }
+}
+static size_t zsa_run_host_batch_devices(bool compress, const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCapacity,
+                                         size_t* outSize, size_t n, int level, const zsa_CDict* cd, const zsa_DDict* dd)
+{
+    unsigned D = (cd || dd || n < 64) ? 1u : zsa_batch_devices();
+    size_t total = 0;
+    if (D > 1) { for (size_t i = 0; i < n; i++) total += srcSize[i] + dstCapacity[i]; if (total < ((size_t)64 << 20)) D = 1; }
+    if (D <= 1) return zsa_run_host_batch(compress, src, srcSize, dst, dstCapacity, outSize, n, level, cd, dd);
+    int cur = 0, count = 0;
+    if (hipGetDevice(&cur) != hipSuccess || hipGetDeviceCount(&count) != hipSuccess || count < 1) { (void)hipGetLastError(); return zsa_fail(ZSA_EF_NO_DEVICE, kErrGeneric); }
+    bool const alias = getenv("ZSTD_AMD_DEVICE_ALIAS") != nullptr;
+    std::lock_guard<std::mutex> g(g_devMutex);
+    try {
+        while (g_devWorkers.size() < D) {
+            ZsaDevWorker* w = new ZsaDevWorker();
+            w->device = alias ? cur : (int)((cur + g_devWorkers.size()) % (size_t)count);
+            w->th = std::thread(zsa_dev_worker_main, w);
+            w->th.detach();                        // (lives as long as the process: bound to its device, holding its staging)
+            g_devWorkers.push_back(w);
+        }
+    } catch (...) { return zsa_run_host_batch(compress, src, srcSize, dst, dstCapacity, outSize, n, level, cd, dd); }
+    // shares of about equal bytes: share d = frames [cut[d], cut[d + 1])
+    std::vector<size_t> cut(D + 1, n);
+    {   size_t acc = 0, d = 1; cut[0] = 0;
+        for (size_t i = 0; i < n && d < D; i++) { acc += srcSize[i] + dstCapacity[i]; if (acc >= total / D * d) cut[d++] = i + 1; }
+    }
+    std::vector<size_t> rc(D, 0); std::vector<int> why(D, 0);
+    for (unsigned d = 0; d < D; d++) {
+        ZsaDevWorker* w = g_devWorkers[d];
+        size_t const a = cut[d], b = cut[d + 1];
+        std::lock_guard<std::mutex> lk(w->m);
+        w->job = [=, &rc, &why] {
+            rc[d] = b > a ? zsa_run_host_batch(compress, src + a, srcSize + a, dst + a, dstCapacity + a, outSize + a, b - a, level, nullptr, nullptr) : 0;
+            why[d] = t_engineFailure;
+        };
+        w->busy = true;
+        w->cv.notify_all();
+    }
+    size_t first = 0;
+    for (unsigned d = 0; d < D; d++) {
+        ZsaDevWorker* w = g_devWorkers[d];
+        std::unique_lock<std::mutex> lk(w->m);
+        w->cv.wait(lk, [&] { return !w->busy; });
+        if (rc[d] && !first) { first = rc[d]; t_engineFailure = why[d]; }
+    }
+    return first;
+}
+
 extern "C" size_t zsa_compress_batch(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCapacity,
                                      size_t* outSize, size_t n, int level, const zsa_CDict* cdict)
-{ return zsa_run_host_batch(true, src, srcSize, dst, dstCapacity, outSize, n, level, cdict, nullptr); }
+{ t_engineFailure = ZSA_EF_NONE; return zsa_run_host_batch_devices(true, src, srcSize, dst, dstCapacity, outSize, n, level, cdict, nullptr); }
 extern "C" size_t zsa_decompress_batch(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCapacity,
                                        size_t* outSize, size_t n, const zsa_DDict* ddict)
-{ return zsa_run_host_batch(false, src, srcSize, dst, dstCapacity, outSize, n, 0, nullptr, ddict); }
+{ t_engineFailure = ZSA_EF_NONE; return zsa_run_host_batch_devices(false, src, srcSize, dst, dstCapacity, outSize, n, 0, nullptr, ddict); }
 
 extern "C" size_t zsa_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level)
 {
