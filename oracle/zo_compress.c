@@ -663,6 +663,7 @@ static size_t zo_compressFrame(u8* dst, size_t dstCapacity, const u8* src, size_
     ms.hashTable = (u32*)calloc((size_t)1 << cp.hlog, sizeof(u32));
     /* zstd_compress.c:236-252 ZSTD_resolveRowMatchFinderMode (SIMD build) and :1977-1996 */
     ms.useRow = (cp.strat >= 3 && cp.strat <= 5) && (cp.wlog > 14);
+    if (cdict != NULL && dictMode != zo_dm_load) ms.useRow = cdict->useRow;   /* :2294, :2364 "cdict overrides" */
     if (cp.strat >= 2 && !ms.useRow) {   /* :262-270: a chain table for every strategy but ZSTD_fast and the row finder */
         ms.chainTable = (u32*)calloc((size_t)1 << cp.clog, sizeof(u32));
         if (!ms.chainTable) { result = ZO_ERR(memory_allocation); goto done; }
@@ -720,6 +721,7 @@ static size_t zo_compressFrame(u8* dst, size_t dstCapacity, const u8* src, size_
             ms.loadedDictEnd = cdict->isLoaded ? cdictEnd : 0;
         }
         *bsPrev = cdict->cbs;   /* :2326 / :2423 copy block state; zo_dm_load parses the same header again (:4942) */
+        ms.nextToUpdate = ms.dictLimit;   /* zstd_compress.c:4596-4600 (a new, non-contiguous segment) */
     }
 
     op += zo_writeFrameHeader(op, cp.wlog, (u64)srcSize, cdict ? cdict->dictID : 0);
@@ -761,8 +763,9 @@ static size_t zo_compressFrame(u8* dst, size_t dstCapacity, const u8* src, size_
                     ms.nextToUpdate = curr - (gap < 192 ? gap : 192);
                 }
             }
-            if (cp.strat >= 3)              lastLL = zo_lazy_noDict(&ms, &ss, bsNext->rep, ip, blockSize, cp.strat - 3);   /* no dictionary at these strategies here */
-            else if (cp.strat == 2)         lastLL = zo_dfast_noDict(&ms, &ss, bsNext->rep, ip, blockSize);   /* no dictionary at this strategy here */
+            if (cp.strat >= 3)              lastLL = zo_lazy_parse(&ms, &ss, bsNext->rep, ip, blockSize, cp.strat - 3);   /* no dictionary, or an attached one */
+            else if (cp.strat == 2 && ms.dms) lastLL = zo_dfast_dictMatchState(&ms, &ss, bsNext->rep, ip, blockSize);
+            else if (cp.strat == 2)         lastLL = zo_dfast_noDict(&ms, &ss, bsNext->rep, ip, blockSize);
             else if (ms.lowLimit < ms.dictLimit) lastLL = zo_fast_extDict(&ms, &ss, bsNext->rep, ip, blockSize);
             else if (ms.dms)                lastLL = zo_fast_dictMatchState(&ms, &ss, bsNext->rep, ip, blockSize);
             else                            lastLL = zo_fast_noDict(&ms, &ss, bsNext->rep, ip, blockSize);

@@ -19,7 +19,11 @@ typedef struct zo_cdict_s {
     int  isLoaded;                        /* 0 when the dictionary was ignored (NULL or < 8 bytes) */
     u32  dictID;
     zo_cparams cp;                        /* cpm_createCDict parameters */
-    u32* hashTable;                       /* tagged: (index << 8) | tag, zstd_fast.c:15-48 */
+    u32* hashTable;                       /* ZSTD_fast / ZSTD_dfast: tagged, (index << 8) | tag (zstd_fast.c:15-48, zstd_double_fast.c:15-49);
+                                           * greedy .. lazy2: plain indices (hash chain heads, or the row finder's cells) */
+    u32* chainTable;                      /* ZSTD_dfast: the short-hash table (tagged); hash-chain finder: the chain */
+    u8*  tagTable;                        /* row finder: one tag byte per cell, byte 0 of a row its head */
+    int  useRow;                          /* cdict->useRowMatchFinder (zstd_compress.c:5420-5468): greedy .. lazy2 with windowLog > 14 */
     u32  endIndex;                        /* window.nextSrc - base == 2 + contentSize */
     zo_cblockstate cbs;                   /* entropy tables + reps loaded from the dictionary */
     int  level;                           /* cdict->compressionLevel */

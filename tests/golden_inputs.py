@@ -54,3 +54,19 @@ def raw_dicts(corpus):
     js = corpus.generate("json", 4096, 10, 9).tobytes()
     return [("raw_7", b"abcdefg"), ("raw_9", b"abcdefghi"), ("raw_log_4k", log[1000:5096]), ("raw_json_40k", js[:40000]),
             ("raw_log_112k", log[:112 * 1024])]
+
+
+def dict_payloads_hi(corpus):
+    """Payloads for the dictionary tests above ZSTD_fast: (name, bytes), up to 40 KiB -- both sides of the attach cut-offs of
+    ZSTD_dfast (16 KiB) and of greedy / lazy / lazy2 (32 KiB), zstd_compress.c:2241-2252."""
+    rnd = random.Random(20261111)
+    out = [p for p in dict_payloads(corpus) if len(p[1]) <= 20000 and p[0] not in ("words1", "words3", "words4", "json78_1k_9", "json78_1k_15", "json78_1k_21")]
+    log = corpus.generate("log", 96 * 1024, 1, 91).tobytes()
+    js = corpus.generate("json", 96 * 1024, 1, 92).tobytes()
+    for i, n in enumerate((300, 1024, 2500, 6000, 12000, 16384, 16385, 24000, 32768, 32769, 40000)):
+        src = log if i & 1 else js
+        o = rnd.randrange(0, len(src) - n)
+        out.append(("%s9%d_%d" % ("log" if i & 1 else "json", 1 + (i & 1), n), src[o:o + n]))
+    out.append(("rep_abc_3000", (b"abcabcabd" * 400)[:3000]))
+    out.append(("zeros_9000", bytes(9000)))
+    return out
