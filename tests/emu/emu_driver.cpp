@@ -78,7 +78,8 @@ static void enc_entry(void* a)
 {
     EncArgs* A = (EncArgs*)a;
     u64 r = (A->P.strat == 1 && !A->cd) ? zsa_encode_frame<2>(A->S, A->ht, A->P, A->src, A->srcSize, A->dst, A->cap, A->W, nullptr, 0)
-          : A->P.strat >= 3 ? zsa_encode_frame<1>(A->S, A->ht, A->P, A->src, A->srcSize, A->dst, A->cap, A->W, A->cd, A->dictMode)
+          : (A->P.strat >= 2 && A->cd) ? zsa_encode_frame<4>(A->S, A->ht, A->P, A->src, A->srcSize, A->dst, A->cap, A->W, A->cd, A->dictMode)
+          : A->P.strat >= 3 ? zsa_encode_frame<1>(A->S, A->ht, A->P, A->src, A->srcSize, A->dst, A->cap, A->W, nullptr, 0)
           : (A->P.strat == 2 && !A->cd) ? zsa_encode_frame<3>(A->S, A->ht, A->P, A->src, A->srcSize, A->dst, A->cap, A->W, nullptr, 0)
                             : zsa_encode_frame<0>(A->S, A->ht, A->P, A->src, A->srcSize, A->dst, A->cap, A->W, A->cd, A->dictMode);
     if (wv_lane() == 0) A->result = r;
@@ -124,7 +125,7 @@ struct DigArgs { ZsaEncShared* SE; ZsaDecShared* SD; EmuCDict* c; EmuDDict* d; u
 static void digc_entry(void* a)
 {
     DigArgs* A = (DigArgs*)a;
-    u32 r = zsa_digest_cdict(A->SE, A->SD, A->c->dict, A->dictSize, A->cp, A->level, &A->c->cd, A->c->table);
+    u32 r = zsa_digest_cdict(A->SE, A->SD, A->c->dict, A->dictSize, A->cp, A->level, &A->c->cd, A->c->table, A->c->table + ((size_t)1 << A->cp.hlog));
     if (wv_lane() == 0) A->result = r;
 }
 static void digd_entry(void* a)
@@ -139,10 +140,10 @@ extern "C" void* emu_create_cdict(const void* dict, size_t n, int level)
 {
     static ZsaEncShared SE; static ZsaDecShared SD;
     ZsaCParams cp;
-    if (zsa_resolveCParams(&cp, level, ZSA_SIZE_UNKNOWN, n, zsa_cpm_createCDict) || cp.strat != 1) return nullptr;
+    if (zsa_resolveCParams(&cp, level, ZSA_SIZE_UNKNOWN, n, zsa_cpm_createCDict)) return nullptr;
     EmuCDict* c = (EmuCDict*)calloc(1, sizeof(EmuCDict));
     c->dict = (u8*)malloc(n + 16); if (n) memcpy(c->dict, dict, n);
-    c->table = (u32*)calloc((size_t)1 << cp.hlog, 4);
+    c->table = (u32*)calloc(((size_t)1 << cp.hlog) + (cp.strat < 2 ? 0 : (zsa_useRowFinder(cp.strat, cp.wlog) ? (size_t)1 << cp.hlog : (size_t)1 << cp.clog)), 4);
     DigArgs A = { &SE, &SD, c, nullptr, (u32)n, cp, level, 0 };
     emu_run_wave(digc_entry, &A);
     if (A.result) { emu_free_cdict(c); return nullptr; }
@@ -161,14 +162,15 @@ extern "C" void* emu_create_ddict(const void* dict, size_t n)
 extern "C" size_t emu_compress_cdict(void* dst, size_t cap, const void* src, size_t n, const void* h)
 {
     static ZsaEncShared S;
-    static u32* ht = (u32*)malloc(sizeof(u32) << 17);
+    static u32* ht = (u32*)malloc(sizeof(u32) << 18);
     static u64* seq = (u64*)malloc(8 * (32768 + 64));
     static u8* lit = (u8*)malloc(ZSA_BLOCKSIZE_MAX + 128);
     static u8* tmp = (u8*)malloc(ZSA_BLOCKSIZE_MAX * 2 + 512);
     static const u8 empty[16] = {0};
     const EmuCDict* c = (const EmuCDict*)h;
     ZsaCParams cp; int mode = 0;
-    if (zsa_resolveCDictUse(&cp, &mode, c->cd.cp, c->cd.level, c->cd.dictSize, n) || cp.strat != 1 || cp.hlog > 17) return (size_t)ZSA_ERR(ZSA_parameter_unsupported);
+    if (zsa_resolveCDictUse(&cp, &mode, c->cd.cp, c->cd.level, c->cd.dictSize, n) || cp.hlog > 17 || cp.clog > 17
+        || !(cp.strat == 1 || (mode == zsa_dm_attach && cp.strat == c->cd.cp.strat))) return (size_t)ZSA_ERR(ZSA_parameter_unsupported);
     EncArgs A = { &S, ht, { cp.wlog, cp.hlog, cp.mml, cp.tlen, cp.clog, cp.strat, cp.slog }, n ? (const u8*)src : empty + 8, n, (u8*)dst, cap, { seq, lit, tmp, nullptr }, &c->cd, mode, 0 };
     emu_run_wave(enc_entry, &A);
     return (size_t)A.result;

@@ -132,6 +132,42 @@ def test_emulated_dictionary_path_matches_golden(emu):
     assert not emu.emu_create_cdict(bad, len(bad), 1) and not emu.emu_create_ddict(bad, len(bad))
 
 
+def test_emulated_dictionary_path_above_fast_matches_golden(emu):
+    """CDict digests for ZSTD_dfast (tagged double hash), the hash chain and the row records; the attached-dictionary parsers
+    of zsa_dict_hi.h and zsa_lazy.h (levels 3 .. 10) -- against the reference-generated fixture tests/golden/dict_cases_hi.json.
+    Payloads above the attach cut-off answer parameter_unsupported."""
+    import hashlib
+    from test_oracle_dict import load_dict_cases_hi
+    dicts, payloads, cases = load_dict_cases_hi()
+    handles = {}
+    served = declined = 0
+    for i, c in enumerate(cases):
+        if i % 3 != (len(c["payload"]) + c["level"]) % 3 and len(payloads[c["payload"]]) < 16000:
+            continue   # a third of the small cases (the GPU test runs them all)
+        key = (c["dict"], c["level"])
+        if key not in handles:
+            d = dicts[c["dict"]]
+            handles[key] = emu.emu_create_cdict(d, len(d), c["level"])
+            assert handles[key] or (c["level"] == 10 and len(d) < 16000), key
+        cd = handles[key]
+        if not cd:
+            continue
+        p = payloads[c["payload"]]
+        cap = zstd_amd.CompressBound(len(p))
+        buf = ctypes.create_string_buffer(cap + 1)
+        n = emu.emu_compress_cdict(buf, cap, p, len(p), cd)
+        if n == 2 ** 64 - 40:
+            assert len(p) > 16384, (c["dict"], c["level"], c["payload"])
+            declined += 1
+            continue
+        served += 1
+        assert n == c["c_len"] and hashlib.sha256(buf.raw[:n]).hexdigest()[:32] == c["c_sha256"], (c["dict"], c["level"], c["payload"], n, c["c_len"])
+    for cd in handles.values():
+        if cd:
+            emu.emu_free_cdict(cd)
+    assert served > 500 and declined > 10, (served, declined)
+
+
 def test_emulated_dictionary_parsers_seeded(emu, oracle):
     """zsa_parse_dict.h against the oracle on seeded payloads the fixture does not hold: the external-segment parser with
     steps that have grown over an incompressible stretch before dictionary content turns up (where the position after a pair

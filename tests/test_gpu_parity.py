@@ -224,6 +224,82 @@ def test_bulk_processor_matches_golden(z):
         assert one == got[2] and bp.Decompress(None, one) == srcs[2]
 
 
+def test_bulk_processor_above_fast_matches_golden(z, oracle):
+    """NewBulkProcessor(dict, level) with level >= 3 (zstd_bulk.go:33-58): CDicts for ZSTD_dfast, the hash chain and the row finder
+    digested on the device, payloads compressed against the ATTACHED dictionary (zsa_dict_hi.h, zsa_lazy.h) -- every
+    reference-generated case of tests/golden/dict_cases_hi.json up to the attach cut-off byte-identical; payloads above it answer
+    parameter_unsupported (-40: the binding's cue for its CPU path), exactly where the oracle declines too."""
+    from test_oracle_dict import load_dict_cases_hi
+    dicts, payloads, cases = load_dict_cases_hi()
+    groups = {}
+    for c in cases:
+        groups.setdefault((c["dict"], c["level"]), []).append(c)
+    served = declined = 0
+    for (dn, level), cs in groups.items():
+        ocd = oracle.cdict(dicts[dn], level)
+        if not ocd:   # a ZSTD_btlazy2 row (level 10 with a dictionary below 16 KB): no digest, the binding stays on the CPU
+            with pytest.raises(z.api.ZstdError):
+                z.NewBulkProcessor(dicts[dn], level)
+            continue
+        bp = z.NewBulkProcessor(dicts[dn], level)
+        srcs = [payloads[c["payload"]] for c in cs]
+        got = bp.CompressBatch(srcs)
+        ok, oks = [], []
+        for c, s, g in zip(cs, srcs, got):
+            want = oracle.compress_cdict(s, ocd)
+            if not isinstance(want, bytes):
+                assert isinstance(g, z.ErrorCode) and g.code == -40 and len(s) > 16384, (dn, level, c["payload"], g)
+                declined += 1
+                continue
+            assert isinstance(g, bytes), (dn, level, c["payload"], g)
+            assert len(g) == c["c_len"] and hashlib.sha256(g).hexdigest()[:32] == c["c_sha256"], (dn, level, c["payload"])
+            ok.append(g); oks.append(s)
+            served += 1
+        oracle.free_cdict(ocd)
+        assert bp.DecompressBatch(ok, [max(len(s), 1) for s in oks]) == oks
+        one = bp.Compress(None, srcs[2])
+        assert one == got[2] and bp.Decompress(None, one) == srcs[2]
+    assert served >= 1600 and declined > 50, (served, declined)
+
+
+def test_bulk_processor_seeded_payloads_above_fast(z, oracle):
+    """Seeded payloads against every fixture dictionary at levels 3 .. 9: dictionary content repeated in the payload (matches that
+    start in the dictionary and run on into the payload, repcodes into the dictionary), incompressible stretches, runs."""
+    from test_oracle_dict import load_dict_cases
+    from zstd_amd import corpus
+    dicts = load_dict_cases()[0]
+    rnd = random.Random(6)
+    compared = 0
+    for dn in sorted(dicts):
+        d = dicts[dn]
+        srcs = []
+        for n in (1, 9, 300, 1024, 4000, 8192, 16384, 16385, 30000, 32768):
+            k = rnd.randrange(5)
+            if k == 0: p = corpus.frames("json", n, 1, rnd.randrange(1000))[0]
+            elif k == 1: p = corpus.frames("log", n, 1, rnd.randrange(1000))[0]
+            elif k == 2: p = ((d[-rnd.randrange(1, min(len(d), 3000) + 1):] + rnd.randbytes(50)) * (n // 200 + 1))[:n]
+            elif k == 3: p = (bytes(rnd.choice(b"abc") for _ in range(n // 3)) + rnd.randbytes(n // 3) + d[:n - 2 * (n // 3)])[:n]
+            else: p = (d[len(d) // 3:len(d) // 3 + 40] * 3 + bytes(100) + d[:60]) * (n // 280 + 1)
+            srcs.append(p[:n])
+        for level in (3, 4, 5, 6, 7, 9):
+            ocd = oracle.cdict(d, level)
+            if not ocd:
+                continue
+            bp = z.NewBulkProcessor(d, level)
+            got = bp.CompressBatch(srcs)
+            ok, oks = [], []
+            for p, g in zip(srcs, got):
+                want = oracle.compress_cdict(p, ocd)
+                if isinstance(want, bytes):
+                    assert g == want, (dn, level, len(p))
+                    ok.append(g); oks.append(p); compared += 1
+                else:
+                    assert isinstance(g, z.ErrorCode) and g.code == -40, (dn, level, len(p), g)
+            oracle.free_cdict(ocd)
+            assert bp.DecompressBatch(ok, [max(len(p), 1) for p in oks]) == oks
+    assert compared > 350
+
+
 def test_bulk_processor_seeded_payloads(z, oracle):
     """Seeded payloads of 1 B .. 300 KB against every fixture dictionary, at the two ZSTD_fast levels the engine serves with a
     dictionary: attached (<= 8 KiB), external segment (above; multi-block payloads, steps that have grown over incompressible

@@ -20,7 +20,7 @@ emu.emu_compress_level.restype = ctypes.c_size_t
 emu.emu_compress_level.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
 emu.emu_decompress.restype = ctypes.c_size_t
 emu.emu_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
-levels = [int(a) for a in sys.argv[1:]] or [1, 3, 5]
+levels = [int(a) for a in sys.argv[1:] if a.lstrip("-").isdigit()] or [1, 3, 5]
 rnd = random.Random(6)
 inputs = [corpus.frames("log", n, 1, 30 + i)[0] for i, n in enumerate([1, 9, 17, 300, 4000, 16385, 100000, 131073, 262145])]
 inputs += [bytes(70000), rnd.randbytes(30000), rnd.randbytes(3000) + bytes(50000) + rnd.randbytes(3000), b"ab" * 20000,
@@ -39,5 +39,36 @@ for level in levels:
             ok = m == len(d) and out.raw[:m] == d
         print("level %d, %d bytes: %s" % (level, len(d), "ok" if ok else "DIFFERS"), flush=True)
         bad += not ok
+# dictionaries: digests and the attached-dictionary parsers at every strategy (payloads and dictionaries in exact-size heap blocks)
+from test_oracle_dict import load_dict_cases
+emu.emu_create_cdict.restype = ctypes.c_void_p
+emu.emu_create_cdict.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
+emu.emu_compress_cdict.restype = ctypes.c_size_t
+emu.emu_compress_cdict.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p]
+emu.emu_free_cdict.argtypes = [ctypes.c_void_p]
+dicts = load_dict_cases()[0]
+if "nodict" not in sys.argv:
+    for dn in sorted(dicts):
+        d = dicts[dn]
+        pl = [corpus.frames("json", n, 1, 50 + i)[0] for i, n in enumerate([1, 9, 300, 1024, 8192, 16384, 30000])]
+        pl += [(d[-min(len(d), 700):] + rnd.randbytes(20)) * 12, d[:min(len(d), 5000)], bytes(3000), rnd.randbytes(2000)]
+        for level in (1, 3, 4, 5, 7, 8):
+            cd = emu.emu_create_cdict(d, len(d), level)
+            ocd = orc.cdict(d, level)
+            if not cd or not ocd:
+                print("dictionary %s level %d: no digest (emu %s, oracle %s)" % (dn, level, bool(cd), bool(ocd)), flush=True)
+                bad += bool(cd) != bool(ocd)
+                continue
+            nbad = 0
+            for p in pl:
+                want = orc.compress_cdict(p, ocd)
+                cap = zstd_amd.CompressBound(len(p))
+                buf = ctypes.create_string_buffer(cap)
+                n = emu.emu_compress_cdict(buf, cap, p, len(p), cd)
+                ok = (buf.raw[:n] == want) if isinstance(want, bytes) else (n == 2 ** 64 + want)
+                nbad += not ok
+            print("dictionary %s (%d bytes), level %d: %s" % (dn, len(d), level, "ok" if not nbad else "%d DIFFER" % nbad), flush=True)
+            bad += nbad
+            emu.emu_free_cdict(cd); orc.free_cdict(ocd)
 print("mismatches", bad)
 sys.exit(1 if bad else 0)

@@ -79,15 +79,17 @@ ZSA_DEV u32 zsa_dictNCountRepeat(const s16* norm, u32 dictMaxSV, u32 maxSV)
     return zsa_rep_valid;
 }
 
-// Returns 0, or an error code (uniform).  `hashTable`: device memory, 1 << cp.hlog words, zero-filled by the caller.
+// Returns 0, or an error code (uniform).  `hashTable`: device memory, 1 << cp.hlog words (row finder: twice that), `chainTable`:
+// 1 << cp.clog words (ZSTD_dfast and the hash-chain finder), both zero-filled by the caller.
 ZSA_DEV u32 zsa_digest_cdict(ZsaEncShared* SE, ZsaDecShared* SD, const u8* dict, u32 dictSize, ZsaCParams cp, int level,
-                             ZsaCDictDev* out, u32* hashTable)
+                             ZsaCDictDev* out, u32* hashTable, u32* chainTable)
 {
     int const lane = wv_lane();
     if (lane == 0) {
         out->content = dict; out->contentSize = 0; out->dictSize = dictSize; out->isLoaded = 0; out->dictID = 0;
         out->level = (level == 0) ? 3 : level;      // zstd_compress.c:5477
-        out->cp = cp; out->hashTable = hashTable;
+        out->cp = cp; out->hashTable = hashTable; out->chainTable = chainTable;
+        out->useRow = zsa_useRowFinder(cp.strat, cp.wlog) ? 1u : 0u;
         out->rep[0] = 1; out->rep[1] = 4; out->rep[2] = 8;   // ZSTD_reset_compressedBlockState :1863-1872
         out->hufRepeat = out->llRepeat = out->ofRepeat = out->mlRepeat = zsa_rep_none;
         SD->err = 0;
@@ -148,6 +150,7 @@ ZSA_DEV u32 zsa_digest_cdict(ZsaEncShared* SE, ZsaDecShared* SD, const u8* dict,
                     SD->u[ZU_tmp] = p + h;
                     // the offset table is built over all MaxOff+1 symbols (:4852-4857); readNCount zero-filled the tail
                     SE->u[EU_s0] = kind == 1 ? ZSA_MaxOff : maxSV;
+                    ct->maxSV = SE->u[EU_s0];   // what ZSTD_fseBitCost checks a block's codes against (zstd_compress_sequences.c:115)
                 }
             }
             wv_sync();
@@ -182,14 +185,15 @@ ZSA_DEV u32 zsa_digest_cdict(ZsaEncShared* SE, ZsaDecShared* SD, const u8* dict,
             ZsaFseCT* const o = kind == 0 ? &out->ll : (kind == 1 ? &out->of : &out->ml);
             for (u32 i = (u32)lane; i < 512; i += ZSA_WAVE) o->nextState[i] = ct->nextState[i];
             for (u32 i = (u32)lane; i <= ZSA_MaxSeq; i += ZSA_WAVE) { o->dfs[i] = ct->dfs[i]; o->dnb[i] = ct->dnb[i]; }
-            if (lane == 0) o->tableLog = ct->tableLog;
+            if (lane == 0) { o->tableLog = ct->tableLog; o->maxSV = ct->maxSV; }
         }
         wv_sync();
     }
     // ---- ZSTD_loadDictionaryContent (tfp_forCDict, dtlm_full)
     const u8* content = dict + contentOff;
     u32 contentSize = dictSize - contentOff;
-    {   u32 const shortCacheMax = (1u << 24) - 2;    // tagged indices keep 24 bits (:4705-4714)
+    if (cp.strat <= 2) {   // ZSTD_CDictIndicesAreTagged
+        u32 const shortCacheMax = (1u << 24) - 2;    // tagged indices keep 24 bits (:4705-4714)
         if (contentSize > shortCacheMax) { content += contentSize - shortCacheMax; contentSize = shortCacheMax; }
     }
     u32 const endIndex = 2 + contentSize;
@@ -197,7 +201,48 @@ ZSA_DEV u32 zsa_digest_cdict(ZsaEncShared* SE, ZsaDecShared* SD, const u8* dict,
     {   u32 const m = cp.hlog > cp.clog ? cp.hlog : cp.clog;
         u32 const maxDictSize = 8u << (m < 28 ? m : 28);
         u32 const from = contentSize > maxDictSize ? endIndex - maxDictSize : 2;
-        if (endIndex - from > 8) {
+        if (endIndex - from > 8 && cp.strat == 2) {
+            // zstd_double_fast.c:15-49: every third position enters both tables, the two in between the long table only, and
+            // only where its cell is still empty -- order-dependent, so lane 0 applies what all lanes have hashed
+            const u8* const dbase = content - 2;
+            u32 const hBitsL = cp.hlog + 8, hBitsS = cp.clog + 8, mls = cp.mml;
+            for (u32 b = from; b + 10 <= endIndex; b += 3 * ZSA_WAVE) {   // ip + 2 <= end - 8  <=>  index + 10 <= endIndex
+                u32 const idx = b + 3 * (u32)lane;
+                if (idx + 10 <= endIndex) {
+                    u64 const v0 = zsa_ld64(dbase + idx);
+                    SD->seqLL[lane] = zsa_hash(v0, hBitsL, 8);
+                    SD->seqML[lane] = zsa_hash(zsa_ld64(dbase + idx + 1), hBitsL, 8);
+                    SD->seqOF[lane] = zsa_hash(zsa_ld64(dbase + idx + 2), hBitsL, 8);
+                    SD->outStart[lane] = zsa_hash(v0, hBitsS, mls);
+                }
+                wv_sync();
+                if (lane == 0) {
+                    for (u32 l = 0; l < ZSA_WAVE; l++) {
+                        u32 const i0 = b + 3 * l;
+                        if (!(i0 + 10 <= endIndex)) break;
+                        u32 const h0 = SD->seqLL[l], h1 = SD->seqML[l], h2 = SD->seqOF[l], hs = SD->outStart[l];
+                        chainTable[hs >> 8] = (i0 << 8) | (hs & 0xFF);
+                        hashTable[h0 >> 8] = (i0 << 8) | (h0 & 0xFF);
+                        if (hashTable[h1 >> 8] == 0) hashTable[h1 >> 8] = ((i0 + 1) << 8) | (h1 & 0xFF);
+                        if (hashTable[h2 >> 8] == 0) hashTable[h2 >> 8] = ((i0 + 2) << 8) | (h2 & 0xFF);
+                    }
+                }
+                wv_sync();
+            }
+        } else if (endIndex - from > 8 && cp.strat >= 3) {
+            // :4767-4786: every position below end - 8 enters the hash chain (zstd_lazy.c:621-646, mls = minMatch) or the rows
+            // (:929-936: hash salt 0, mls capped at 6, no gap rule), 64 positions per step as in the parsers (zsa_lazy.h)
+            ZsaLazyCtx C;
+            C.S = SE; C.hashTable = hashTable; C.chainTable = chainTable; C.base = content - 2;
+            C.hlog = cp.hlog; C.clog = cp.clog; C.wlog = cp.wlog; C.slog = cp.slog;
+            C.rowLog = cp.slog < 4 ? 4 : (cp.slog > 6 ? 6 : cp.slog);
+            C.rowHashLog = cp.hlog - C.rowLog;
+            C.useRow = zsa_useRowFinder(cp.strat, cp.wlog);
+            C.mls = C.useRow ? (cp.mml < 6 ? cp.mml : 6) : cp.mml;
+            C.lowLimit = 2; C.nextToUpdate = from; C.lazySkipping = 0; C.cN = 0; C.cBase = 0; C.cTag = C.cCell = C.cRel = 0;
+            if (C.useRow) zsa_row_insert_range(C, from, endIndex - 8, (1u << C.rowLog) - 1u, lane, 0);
+            else (void)zsa_hc_insertAndFind(C, content + contentSize - 8, 0, lane);
+        } else if (endIndex - from > 8) {
             // zstd_fast.c:15-48.  Loop bound: ip + 3 < (end - 8) + 2  <=>  index + 9 < endIndex.  All lanes hash a
             // batch of 64 triples (coalesced reads of the content); lane 0 then applies them in the reference's order,
             // because "insert only into an empty cell" makes the result order-dependent.

@@ -39,7 +39,10 @@ struct ZsaCDictDev {            // digested compression dictionary, device resid
     u32 dictID;
     s32 level;                  // cdict->compressionLevel
     ZsaCParams cp;              // cpm_createCDict parameters
-    const u32* hashTable;       // tagged: (index << 8) | tag, 1 << cp.hlog entries
+    const u32* hashTable;       // ZSTD_fast / ZSTD_dfast: tagged cells, (index << 8) | tag, 1 << cp.hlog of them; hash-chain finder: the
+                                // chain heads; row finder: the row records (tags, then cells: zsa_lazy.h), 8 << cp.hlog bytes
+    const u32* chainTable;      // ZSTD_dfast: the short-hash table (tagged, 1 << cp.clog cells); hash-chain finder: the chain
+    u32 useRow;                 // cdict->useRowMatchFinder: greedy .. lazy2 with the CDict's windowLog > 14 (zstd_compress.c:5445-5447)
     u32 rep[3];
     u32 hufRepeat, llRepeat, ofRepeat, mlRepeat;
     ZsaHufCT huf;
@@ -150,7 +153,6 @@ ZSA_DEV u32 zsa_hash(u64 v, u32 hBits, u32 mls)
 }
 #include "zsa_parse.h"
 #include "zsa_dfast.h"
-#include "zsa_lazy.h"
 
 // window of one frame (zstd_compress_internal.h ZSTD_window_t + the match-state fields the fast parsers read)
 struct ZsaWindow {
@@ -161,6 +163,8 @@ struct ZsaWindow {
 };
 
 #include "zsa_parse_dict.h"   // parse with an attached dictionary (zstd_fast.c:459-656), wave-level
+#include "zsa_lazy.h"         // greedy / lazy / lazy2, without a dictionary and with an attached one
+#include "zsa_dict_hi.h"      // ZSTD_dfast with an attached dictionary (zstd_double_fast.c:309-532)
 
 // ------------------------------------------------------------------ FSE (fse_compress.c)
 ZSA_DEV u32 zsa_fse_minTableLog(u32 srcSize, u32 maxSV)
@@ -1109,7 +1113,9 @@ ZSA_DEV u32 zsa_entropyCompress(ZsaEncShared* S, const u64* seq, u32 nbSeq, cons
                 // compressed block of this frame
                 const ZsaFseCT* const dt = cd ? (kind == 0 ? &cd->ll : (kind == 1 ? &cd->of : &cd->ml)) : (park ? park + kind : (const ZsaFseCT*)0);
                 wv_lds_fence();
-                u32 const type = zsa_selectEncodingType(S, &rmv, S->count, max, mostFrequent, nbSeq, kind, cd ? (const ZsaFseCT*)0 : dt, tmp, defaultAllowed, strategy, lane);
+                // (below ZSTD_lazy the choice never prices the previous table, :180-205; from ZSTD_lazy on it does -- with a dictionary that
+                // is the dictionary's table: such frames have one block, the attach cut-off is 32 KiB)
+                u32 const type = zsa_selectEncodingType(S, &rmv, S->count, max, mostFrequent, nbSeq, kind, (cd && strategy < 4) ? (const ZsaFseCT*)0 : dt, tmp, defaultAllowed, strategy, lane);
                 u32 const lastCode = kind == 0 ? zsa_LLcode(zsa_seq_ll(lastSeq)) : (kind == 1 ? zsa_highbit32(zsa_seq_of(lastSeq)) : zsa_MLcode(zsa_seq_ml(lastSeq)));
                 u32 const firstCode = kind == 0 ? zsa_LLcode(zsa_seq_ll(firstSeq)) : (kind == 1 ? zsa_highbit32(zsa_seq_of(firstSeq)) : zsa_MLcode(zsa_seq_ml(firstSeq)));
                 ZsaFseCT* const ct = kind == 0 ? &S->ll : (kind == 1 ? &S->of : &S->ml);
@@ -1294,8 +1300,9 @@ ZSA_DEV void zsa_gatherLiterals(ZsaEncShared* S, const u64* seq, u32 nbSeq, cons
 struct ZsaEncScratch { u64* seq; u8* lit; u8* tmp; ZsaFseCT* park; };   // park: 3 sequence tables (LL, OF, ML) of the last compressed block
 
 // FAMILY 0: ZSTD_fast with a dictionary; FAMILY 1: ZSTD_greedy / ZSTD_lazy / ZSTD_lazy2; FAMILY 2: ZSTD_fast without a
-// dictionary (levels 1, 2 and below: the headline path); FAMILY 3: ZSTD_dfast.  Each is compiled into a kernel of its own: each parser
-// then gets the whole register budget (one kernel holding two of them spilled).
+// dictionary (levels 1, 2 and below: the headline path); FAMILY 3: ZSTD_dfast; FAMILY 4: ZSTD_dfast .. ZSTD_lazy2 with an attached
+// dictionary (BulkProcessor at levels 3 and up, payloads up to the attach cut-off).  Each is compiled into a kernel of its own:
+// each parser then gets the whole register budget (one kernel holding two of them spilled).
 template <int FAMILY>
 ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams& P, const u8* src, u64 srcSize64,
                              u8* dst, u64 dstCapacity, const ZsaEncScratch& W, const ZsaCDictDev* cd, int dictMode)
@@ -1342,7 +1349,7 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
     } else {
         // ZSTD_dfast: the short-hash ("chain") table follows the long one in the same scratch region; greedy/lazy/lazy2: the
         // chain table, or the row finder's tag table (one byte per cell)
-        u32 const cells = (1u << P.hlog) + zsa_auxTableBytes(P.strat, P.wlog, P.hlog, P.clog) / 4u;
+        u32 const cells = (1u << P.hlog) + (FAMILY == 4 ? (P.strat < 2 ? 0u : ((cd->useRow ? 4u << P.hlog : 4u << P.clog))) : zsa_auxTableBytes(P.strat, P.wlog, P.hlog, P.clog)) / 4u;
         for (u32 i = 4u * (u32)lane; i < cells; i += 4u * ZSA_WAVE) { hashTable[i] = 0; hashTable[i + 1] = 0; hashTable[i + 2] = 0; hashTable[i + 3] = 0; }
     }
     if (cd) {
@@ -1415,9 +1422,15 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
     LZ.mls = P.mml < 4 ? 4 : (P.mml > 6 ? 6 : P.mml);
     LZ.rowLog = P.slog < 4 ? 4 : (P.slog > 6 ? 6 : P.slog);
     LZ.rowHashLog = P.hlog - LZ.rowLog;                             // zstd_compress.c:1991-1995
-    LZ.useRow = zsa_useRowFinder(P.strat, P.wlog);
+    LZ.useRow = FAMILY == 4 ? (cd->useRow != 0 && P.strat >= 3) : zsa_useRowFinder(P.strat, P.wlog);   // zstd_compress.c:2294 "cdict overrides"
     LZ.lowLimit = Wn.lowLimit; LZ.nextToUpdate = Wn.dictLimit;      // zstd_compress.c:4596-4600
     LZ.lazySkipping = 0;
+    LZ.dms = nullptr; LZ.dmsDelta = 0; LZ.V.base = Wn.base; LZ.V.dbase = Wn.base; LZ.V.prefix = Wn.dictLimit; LZ.V.dictLow = Wn.dictLimit;
+    if (FAMILY == 4 && Wn.dms) {
+        LZ.dms = Wn.dms;
+        LZ.dmsDelta = Wn.dictLimit - (2u + Wn.dms->contentSize);
+        LZ.V.dbase = (Wn.dms->content - 2) - LZ.dmsDelta; LZ.V.dictLow = 2u + LZ.dmsDelta;
+    }
     u32 tablesBuilt = 0;
     u32 remaining = srcSize;
     const u8* ip = src;
@@ -1487,14 +1500,26 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
                 wv_sync();
                 u32 rep[3] = { S->prevRep[0], S->prevRep[1], S->prevRep[2] };
                 u32 lastLL = 0, nbSeq;
-                if (FAMILY == 1) {   // greedy / lazy / lazy2 (never with a dictionary here): wave-uniform, zsa_lazy.h
+                if (FAMILY == 4 && Wn.dms) {   // attached dictionary above ZSTD_fast (one block: payloads up to the attach cut-off)
+                    if (P.strat == 2) {
+                        u32* const io = &S->u[EU_s0];
+                        if (lane == 0) { io[0] = rep[0]; io[1] = rep[1]; io[2] = 0; }
+                        wv_sync();
+                        nbSeq = wv_uniform(zsa_parse_dfast_dms(hashTable, hashTable + (1u << P.hlog), P.hlog, P.clog, P.mml, Wn.base, Wn.dictLimit, Wn.dms,
+                                                               ip, blockSize, io, W.seq));
+                        wv_sync();
+                        rep[0] = io[0]; rep[1] = io[1]; lastLL = io[2];
+                    } else {
+                        nbSeq = zsa_parse_lazy<true>(LZ, Wn.dictLimit, ip, blockSize, P.strat - 3, rep, W.seq, &lastLL, lane);
+                    }
+                } else if (FAMILY == 1 || (FAMILY == 4 && P.strat >= 3)) {   // greedy / lazy / lazy2 without a dictionary segment: wave-uniform, zsa_lazy.h
                     // the greedy chunk path's row bitmap lies in `dupBits`, which overlays the last block's FSE tables (parked in
                     // global scratch from ZSTD_lazy on, never used again below it), not the Huffman table carried from block to block
                     if (P.strat == 3) for (u32 i = (u32)lane; i < sizeof(S->dupBits) / 4; i += ZSA_WAVE) S->dupBits[i] = 0;
                     wv_sync();
-                    nbSeq = zsa_parse_lazy(LZ, Wn.dictLimit, ip, blockSize, P.strat - 3, rep, W.seq, &lastLL, lane);
+                    nbSeq = zsa_parse_lazy<false>(LZ, Wn.dictLimit, ip, blockSize, P.strat - 3, rep, W.seq, &lastLL, lane);
                     ZSA_SEQ_HOOK(W.seq, nbSeq);
-                } else if (FAMILY == 3) {   // ZSTD_dfast (never with a dictionary here): wave-level, zsa_dfast.h
+                } else if (FAMILY == 3 || FAMILY == 4) {   // ZSTD_dfast without a dictionary segment: wave-level, zsa_dfast.h
                     // its two cell bitmaps lie in `filt`, which overlays table-construction scratch and the last block's FSE tables
                     // (never used again below ZSTD_lazy), not the Huffman table that is carried from block to block
                     for (u32 i = (u32)lane; i < sizeof(S->filt) / 4; i += ZSA_WAVE) S->filt[i] = 0;
@@ -1551,7 +1576,7 @@ ZSA_DEV u64 zsa_encode_frame(ZsaEncShared* S, u32* hashTable, const ZsaEncParams
             ZSA_PROF(S, lane, 2);
             // (FAMILY 0: the strategy is 1 or 2, which folds the cost-based mode selection out of that kernel)
             u32 const strat = (FAMILY == 2 || FAMILY == 0) ? 1u : (FAMILY == 3 ? 2u : P.strat);
-            if (FAMILY == 1) cSize = zsa_entropyCompress(S, W.seq, nbSeq, W.lit, litSize, op + 3, blockSize, W.tmp, literalsDisabled, cd, strat,
+            if (FAMILY == 1 || FAMILY == 4) cSize = zsa_entropyCompress(S, W.seq, nbSeq, W.lit, litSize, op + 3, blockSize, W.tmp, literalsDisabled, cd, strat,
                                                          (P.strat >= 4 && !cd) ? W.park : (const ZsaFseCT*)0, lane);
             else cSize = wv_uniform(zsa_entropyCompress_fn(S, W.seq, nbSeq, W.lit, litSize, op + 3, blockSize, W.tmp, literalsDisabled, cd, strat));
             if (S->err) return ZSA_ERR(S->err);

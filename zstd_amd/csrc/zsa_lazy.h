@@ -83,6 +83,11 @@ struct ZsaLazyCtx {
     // into a row patches the cached copy, a table update after a match drops it.
     u32 cBase, cN;
     u32 cTag, cCell, cRel;
+    // attached dictionary (ZSTD_dictMatchState; read by the <true> instantiations only): its digest, and dictionary + payload as
+    // one index space (zsa_parse_dict.h) -- a dictionary index d is the joint index d + dmsDelta, right below the payload's
+    const ZsaCDictDev* dms;
+    ZsaDmsView V;
+    u32 dmsDelta;
 };
 
 // 16 source bytes at `p`, kept in registers: literal runs are searched position after position, and the bytes a position
@@ -135,6 +140,34 @@ ZSA_DEV void zsa_lazy_evaluate(const ZsaLazyCtx& C, const u8* ip, const u8* iLim
     }
 }
 
+// zstd_compress_internal.h:780-793 ZSTD_count_2segments by one lane's loads: a match that starts in the dictionary [.., mEnd) and
+// may run on into the payload from iStart
+ZSA_DEV u32 zsa_lz_count_2segments(const u8* ip, const u8* match, const u8* iEnd, const u8* mEnd, const u8* iStart)
+{
+    const u8* const vEnd = (ip + (mEnd - match) < iEnd) ? ip + (mEnd - match) : iEnd;
+    u32 const n = zsa_lz_count(ip, match, vEnd);
+    if (match + n != mEnd) return n;
+    return n + zsa_lz_count(ip + n, iStart, iEnd);
+}
+// The same selection over candidates of the attached dictionary (zstd_lazy.c:739-757, :1291-1309): myIndex is an index of the
+// dictionary's own window; a candidate counts only if its first 4 bytes agree (a full measurement of one that does not stays
+// below 4, never above ml >= 3); the offset is taken in the joint index space.
+ZSA_DEV void zsa_lazy_evaluate_dms(const ZsaLazyCtx& C, const u8* ip, const u8* iLimit, u32 curr, u32 myIndex, u32 nCand,
+                                   u32* ml, u32* offBasePtr, int lane)
+{
+    if (nCand == 0) return;
+    bool const mine = (u32)lane < nCand;
+    const u8* const dmsBase = C.dms->content - 2;
+    const u8* const dmsEnd = C.dms->content + C.dms->contentSize;
+    u32 const len = mine ? zsa_lz_count_2segments(ip, dmsBase + myIndex, iLimit, dmsEnd, C.base + C.V.prefix) : 0u;
+    u32 best = *ml, which = ZSA_WAVE;
+    for (u32 k = 0; k < nCand; k++) { u32 const l = wv_readlane(len, (int)k); if (l > best) { best = l; which = k; } }
+    if (which < ZSA_WAVE) {
+        *ml = best;
+        *offBasePtr = (curr - (wv_readlane(myIndex, (int)which) + C.dmsDelta)) + 3;
+    }
+}
+
 // ---------------------------------------------------------------- hash chain
 // zstd_lazy.c:621-646 ZSTD_insertAndFindFirstIndex_internal: positions [nextToUpdate, target) enter the chain, 64 per
 // step (lane k takes position b + k).  A position's predecessor is the cell's old content, or the nearest earlier
@@ -166,6 +199,7 @@ ZSA_DEV u32 zsa_hc_insertAndFind(ZsaLazyCtx& C, const u8* ip, u64 vip, int lane)
 }
 // zstd_lazy.c:655-761 ZSTD_HcFindBestMatch, noDict.  Returns the best length (3 = none), offBase in *offBasePtr.
 // The chain is walked first (its course depends on indices only), 64 candidates at a time, then measured by all lanes.
+template <bool DMS>
 ZSA_DEV u32 zsa_hc_findBestMatch(ZsaLazyCtx& C, const u8* ip, u64 vip, const u8* iLimit, u32* offBasePtr, int lane)
 {
     u32 const chainSize = 1u << C.clog, chainMask = chainSize - 1u;
@@ -181,13 +215,35 @@ ZSA_DEV u32 zsa_hc_findBestMatch(ZsaLazyCtx& C, const u8* ip, u64 vip, const u8*
         u32 myIndex = 0, nCand = 0;
         while (more && nCand < ZSA_WAVE) {
             if ((u32)lane == nCand) myIndex = matchIndex;
-            nCand++; nbAttempts--;
-            if (matchIndex <= minChain) { more = false; break; }
+            nCand++;
+            if (matchIndex <= minChain) { more = false; break; }   // (leaves the loop without using up an attempt, :718)
+            nbAttempts--;
             matchIndex = wv_ldg_cell(C.chainTable + (matchIndex & chainMask));
             more = (matchIndex >= lowLimit) & (nbAttempts > 0);
         }
         zsa_lazy_evaluate(C, ip, iLimit, curr, myIndex, nCand, &ml, offBasePtr, lane);
         if (ip + ml == iLimit) break;   // :715 best possible
+    }
+    if constexpr (DMS) {   // :726-758 the dictionary's chain, with what is left of the attempts (tables read-only, shared by all frames)
+        const u32* const dmsChain = C.dms->chainTable;
+        u32 const dmsChainSize = 1u << C.dms->cp.clog, dmsChainMask = dmsChainSize - 1u;
+        u32 const dmsSize = 2u + C.dms->contentSize;
+        u32 const dmsMinChain = dmsSize > dmsChainSize ? dmsSize - dmsChainSize : 0;
+        matchIndex = wv_ldg_cell(C.dms->hashTable + zsa_hash(vip, C.dms->cp.hlog, C.mls));
+        more = (matchIndex >= 2u) & (nbAttempts > 0);
+        while (more) {
+            u32 myIndex = 0, nCand = 0;
+            while (more && nCand < ZSA_WAVE) {
+                if ((u32)lane == nCand) myIndex = matchIndex;
+                nCand++;
+                if (matchIndex <= dmsMinChain) { more = false; break; }
+                nbAttempts--;
+                matchIndex = wv_ldg_cell(dmsChain + (matchIndex & dmsChainMask));
+                more = (matchIndex >= 2u) & (nbAttempts > 0);
+            }
+            zsa_lazy_evaluate_dms(C, ip, iLimit, curr, myIndex, nCand, &ml, offBasePtr, lane);
+            if (ip + ml == iLimit) break;
+        }
     }
     return ml;
 }
@@ -211,14 +267,14 @@ ZSA_DEV void zsa_row_put(ZsaLazyCtx& C, u32 relRow, u32 tag, u32 idx, u32 rowMas
 // that falls into a row takes the slot r steps behind the row's head, and the last one leaves the head there; a position
 // whose slot a later position of the same step takes again (rowEntries-1 or more later ones in its row: runs of equal
 // bytes) is not stored at all, which is what overwriting would have left.
-ZSA_DEV void zsa_row_insert_range(ZsaLazyCtx& C, u32 from, u32 to, u32 rowMask, int lane)
-{
+ZSA_DEV void zsa_row_insert_range(ZsaLazyCtx& C, u32 from, u32 to, u32 rowMask, int lane, u64 const salt = ZSA_FRESH_HASH_SALT)
+{   // (salt: a frame's context has the fresh one, a dictionary's tables are built with 0, zstd_compress.c:1985-1990)
     if (from < to) C.cN = 0;
     for (u32 b = from; b < to; b += ZSA_WAVE) {
         u32 const n = (to - b) < ZSA_WAVE ? (to - b) : ZSA_WAVE;
         bool const act = (u32)lane < n;
         u32 const pos = b + (act ? (u32)lane : 0u);
-        u32 const hash = zsa_hash_salted(wv_ldg64(C.base + pos), C.rowHashLog + 8, C.mls, ZSA_FRESH_HASH_SALT);
+        u32 const hash = zsa_hash_salted(wv_ldg64(C.base + pos), C.rowHashLog + 8, C.mls, salt);
         u32 const relRow = (hash >> 8) << C.rowLog;
         u8* const tagRow = zsa_row_tags(C, relRow);
         u32 const head0 = wv_ldg8(tagRow) & rowMask;
@@ -248,6 +304,7 @@ ZSA_DEV void zsa_row_update(ZsaLazyCtx& C, const u8* ip, u32 rowMask, int lane)
     C.nextToUpdate = target;
 }
 // zstd_lazy.c:1120-1313 ZSTD_RowFindBestMatch, noDict
+template <bool DMS>
 ZSA_DEV u32 zsa_row_findBestMatch(ZsaLazyCtx& C, const u8* ip, u64 vip, const ZsaSrcWin& W, const u8* iLimit, u32* offBasePtr, int lane)
 {
     u32 const curr = (u32)(ip - C.base);
@@ -311,12 +368,66 @@ ZSA_DEV u32 zsa_row_findBestMatch(ZsaLazyCtx& C, const u8* ip, u64 vip, const Zs
     ZSA_PPROF(C.S, lane, 9);
     zsa_lazy_evaluate(C, ip, iLimit, curr, myIndex, nCand, &ml, offBasePtr, lane);   // :1232-1258
     ZSA_PPROF(C.S, lane, 10);
+    if constexpr (DMS) {   // :1171-1181, :1265-1311 the dictionary's row (unsalted hash, its own hash width), remaining attempts
+        u32 const left = nbAttempts - nCand;
+        u32 const dmsHash = zsa_hash(vip, (C.dms->cp.hlog - C.rowLog) + 8, C.mls);
+        u32 const dmsRel = (dmsHash >> 8) << C.rowLog;
+        const u8* const dTags = (const u8*)C.dms->hashTable + ((size_t)dmsRel << 3);
+        const u32* const dCells = (const u32*)(dTags + ((size_t)1 << C.rowLog));
+        u32 const p = (u32)lane & rowMask;
+        u32 const dTag = wv_ldg8(dTags + p), dCell = wv_ldg_cell(dCells + p);
+        u64 deq = wv_ballot(dTag == (dmsHash & 0xFF));
+        if (rowEntries < 64) deq &= (((u64)1 << rowEntries) - 1u);
+        u32 const dHead = wv_readlane(dTag, 0) & rowMask;
+        u32 dIndex = 0, dCand = 0;
+        {   u64 rot = dHead ? ((deq >> dHead) | (deq << (rowEntries - dHead))) : deq;
+            if (rowEntries < 64) rot &= (((u64)1 << rowEntries) - 1u);
+            for (; rot && dCand < left; rot &= rot - 1) {
+                u32 const matchPos = (dHead + (u32)__builtin_ctzll(rot)) & rowMask;
+                if (matchPos == 0) continue;
+                u32 const matchIndex = wv_readlane(dCell, (int)matchPos);
+                if (matchIndex < 2u) break;
+                if ((u32)lane == dCand) dIndex = matchIndex;
+                dCand++;
+            }
+        }
+        zsa_lazy_evaluate_dms(C, ip, iLimit, curr, dIndex, dCand, &ml, offBasePtr, lane);
+    }
     return ml;
 }
 
+template <bool DMS>
 ZSA_DEV u32 zsa_searchMax(ZsaLazyCtx& C, const u8* ip, u64 vip, const ZsaSrcWin& W, const u8* iend, u32* offBasePtr, int lane)
 {   // zstd_lazy.c:1466-1487; vip = the 8 bytes at ip, W = the source window they came from
-    return C.useRow ? zsa_row_findBestMatch(C, ip, vip, W, iend, offBasePtr, lane) : zsa_hc_findBestMatch(C, ip, vip, iend, offBasePtr, lane);
+    return C.useRow ? zsa_row_findBestMatch<DMS>(C, ip, vip, W, iend, offBasePtr, lane) : zsa_hc_findBestMatch<DMS>(C, ip, vip, iend, offBasePtr, lane);
+}
+
+// zstd_lazy.c:1565-1577 and its repeats (:1618-1632, :1654-1668, :1714-1733): the repcode candidate `offset` behind index `ip`
+// with an attached dictionary -- its source may lie in the dictionary, or start there and run on into the payload.  Returns the
+// match length, 0 for none.  Uniform arguments, all lanes (the count takes 64 bytes per round trip in the joint index space).
+ZSA_DEV u32 zsa_lazy_dmsRep(const ZsaLazyCtx& C, u32 ip, u32 offset, u32 iend, int lane)
+{
+    u32 const repIndex = ip - offset;
+    if ((u32)((C.V.prefix - 1u) - repIndex) < 3u) return 0;   // (intentional wrap: the 4 bytes would straddle the prefix start)
+    if (zsa_dv32(C.V, repIndex) != wv_ldg32(C.base + ip)) return 0;
+    return zsa_dv_count(C.V, ip + 4, repIndex + 4, iend, lane) + 4;
+}
+// :1691-1696 catch up in the joint index space: bytes in front of (start, match) that agree, start above anchor, match above
+// the start of its segment
+ZSA_DEV u32 zsa_lazy_dmsCatchup(const ZsaLazyCtx& C, u32 start, u32 matchIndex, u32 anchor, int lane)
+{
+    u32 const mStart = matchIndex < C.V.prefix ? C.V.dictLow : C.V.prefix;
+    u32 const roomA = start - anchor, roomM = matchIndex - mStart;
+    u32 const room = roomA < roomM ? roomA : roomM;
+    u32 total = 0;
+    while (total < room) {
+        u32 const k = total + (u32)lane;
+        bool const same = k < room && wv_ldg8(C.base + start - 1 - k) == zsa_dv8(C.V, matchIndex - 1 - k);
+        u64 const stop = wv_ballot(!same);
+        if (stop) return total + (u32)__builtin_ctzll(stop);
+        total += ZSA_WAVE;
+    }
+    return room;
 }
 
 // ---------------------------------------------------------------- greedy parse with the row finder, 64 positions at a time
@@ -608,6 +719,7 @@ ZSA_DEVFN void zsa_greedy_row_chunk(ZsaGreedyState* stp, u64* seqOutIn, u32 iend
 
 // depth 0 = greedy, 1 = lazy, 2 = lazy2 (zstd_lazy.c:1493-1757).  Appends packed sequences to seqOut, returns their
 // number; rep[] and *lastLL are updated.  Called by all lanes with uniform arguments; everything it computes is uniform.
+template <bool DMS>
 ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcSize, u32 depth, u32 rep[3], u64* seqOut, u32* lastLL, int lane)
 {
     const u8* const istart = src;
@@ -621,8 +733,8 @@ ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcS
 #define ZSA_UPTO_LIMIT(p)   ((s32)(iend - (p)) >= margin)     /* p <= ilimit */
 #define ZSA_HB(x) (31u - (u32)__builtin_clz((u32)(x)))
 
-    ip += (ip == prefixLowest);
-    {   u32 const curr = (u32)(ip - C.base);
+    if constexpr (!DMS) ip += (ip == prefixLowest);   // (:1526-1529; an attached dictionary is never empty)
+    if constexpr (!DMS) {   u32 const curr = (u32)(ip - C.base);
         u32 const maxDistance = 1u << C.wlog;
         u32 const windowLow = (curr - dictLimit > maxDistance) ? curr - maxDistance : dictLimit;   // ZSTD_getLowestPrefixIndex
         u32 const maxRep = curr - windowLow;
@@ -638,8 +750,9 @@ ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcS
 #ifdef ZSA_NO_GREEDY_CHUNK
     bool const chunks = false;
 #else
-    bool const chunks = depth == 0 && C.useRow && C.rowLog <= 5 && (C.slog < C.rowLog ? C.slog : C.rowLog) <= 3;
+    bool const chunks = !DMS && depth == 0 && C.useRow && C.rowLog <= 5 && (C.slog < C.rowLog ? C.slog : C.rowLog) <= 3;
 #endif
+    u32 const iendIdx = (u32)(iend - C.base);
     u32 hold = 0;
     while (ZSA_BEFORE_LIMIT(ip)) {
         if (chunks && !C.lazySkipping) {
@@ -665,14 +778,18 @@ ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcS
 
         // the bytes at ip serve the repcode check at ip+1 and the search at ip; both loads share a round trip
         u64 vip = zsa_win_get64(W, ip, iend);
-        // :1578-1582 repcode at ip+1
+        // :1565-1582 repcode at ip+1
+        if constexpr (DMS) {
+            u32 const mlRep = zsa_lazy_dmsRep(C, (u32)(ip - C.base) + 1, offset_1, iendIdx, lane);
+            if (mlRep) { matchLength = mlRep; if (depth == 0) storeNow = true; }
+        } else
         if ((offset_1 > 0) && (zsa_win_get32(R, ip + 1 - offset_1, iend) == (u32)(vip >> 8))) {
             matchLength = zsa_lz_count(ip + 1 + 4, ip + 1 + 4 - offset_1, iend) + 4;
             if (depth == 0) storeNow = true;
         }
         if (!storeNow) {
             {   u32 offbaseFound = 999999999;   // :1585-1589
-                u32 const ml2 = zsa_searchMax(C, ip, vip, W, iend, &offbaseFound, lane);
+                u32 const ml2 = zsa_searchMax<DMS>(C, ip, vip, W, iend, &offbaseFound, lane);
                 if (ml2 > matchLength) { matchLength = ml2; start = ip; offBase = offbaseFound; }
             }
             if (matchLength < 4) {   // :1591-1603
@@ -685,6 +802,12 @@ ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcS
             while (ZSA_BEFORE_LIMIT(ip)) {   // :1606-1678
                 ip++;
                 vip = zsa_win_get64(W, ip, iend);
+                if constexpr (DMS) {   // :1618-1632
+                    u32 const mlRep = zsa_lazy_dmsRep(C, (u32)(ip - C.base), offset_1, iendIdx, lane);
+                    s32 const gain2 = (s32)(mlRep * 3);
+                    s32 const gain1 = (s32)(matchLength * 3 - ZSA_HB(offBase) + 1);
+                    if ((mlRep >= 4) && (gain2 > gain1)) { matchLength = mlRep; offBase = 1; start = ip; }
+                } else
                 if ((offBase) && ((offset_1 > 0) && ((u32)vip == zsa_win_get32(R, ip - offset_1, iend)))) {
                     u32 const mlRep = zsa_lz_count(ip + 4, ip + 4 - offset_1, iend) + 4;
                     s32 const gain2 = (s32)(mlRep * 3);
@@ -692,7 +815,7 @@ ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcS
                     if ((mlRep >= 4) && (gain2 > gain1)) { matchLength = mlRep; offBase = 1; start = ip; }
                 }
                 {   u32 ofbCandidate = 999999999;
-                    u32 const ml2 = zsa_searchMax(C, ip, vip, W, iend, &ofbCandidate, lane);
+                    u32 const ml2 = zsa_searchMax<DMS>(C, ip, vip, W, iend, &ofbCandidate, lane);
                     s32 const gain2 = (s32)(ml2 * 4 - ZSA_HB(ofbCandidate));
                     s32 const gain1 = (s32)(matchLength * 4 - ZSA_HB(offBase) + 4);
                     if ((ml2 >= 4) && (gain2 > gain1)) { matchLength = ml2; offBase = ofbCandidate; start = ip; continue; }
@@ -700,6 +823,12 @@ ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcS
                 if ((depth == 2) && ZSA_BEFORE_LIMIT(ip)) {
                     ip++;
                     vip = zsa_win_get64(W, ip, iend);
+                    if constexpr (DMS) {   // :1654-1668
+                        u32 const mlRep = zsa_lazy_dmsRep(C, (u32)(ip - C.base), offset_1, iendIdx, lane);
+                        s32 const gain2 = (s32)(mlRep * 4);
+                        s32 const gain1 = (s32)(matchLength * 4 - ZSA_HB(offBase) + 1);
+                        if ((mlRep >= 4) && (gain2 > gain1)) { matchLength = mlRep; offBase = 1; start = ip; }
+                    } else
                     if ((offBase) && ((offset_1 > 0) && ((u32)vip == zsa_win_get32(R, ip - offset_1, iend)))) {
                         u32 const mlRep = zsa_lz_count(ip + 4, ip + 4 - offset_1, iend) + 4;
                         s32 const gain2 = (s32)(mlRep * 4);
@@ -707,7 +836,7 @@ ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcS
                         if ((mlRep >= 4) && (gain2 > gain1)) { matchLength = mlRep; offBase = 1; start = ip; }
                     }
                     {   u32 ofbCandidate = 999999999;
-                        u32 const ml2 = zsa_searchMax(C, ip, vip, W, iend, &ofbCandidate, lane);
+                        u32 const ml2 = zsa_searchMax<DMS>(C, ip, vip, W, iend, &ofbCandidate, lane);
                         s32 const gain2 = (s32)(ml2 * 4 - ZSA_HB(ofbCandidate));
                         s32 const gain1 = (s32)(matchLength * 4 - ZSA_HB(offBase) + 7);
                         if ((ml2 >= 4) && (gain2 > gain1)) { matchLength = ml2; offBase = ofbCandidate; start = ip; continue; }
@@ -717,8 +846,9 @@ ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcS
             }
             if (offBase > 3) {   // :1685-1698 catch up
                 u32 const off = offBase - 3;
-                const u8* const m = start - off;
-                u32 const back = zsa_lazy_catchup(start, m, anchor, prefixLowest);
+                u32 back;
+                if constexpr (DMS) back = zsa_lazy_dmsCatchup(C, (u32)(start - C.base), (u32)(start - C.base) - off, (u32)(anchor - C.base), lane);
+                else back = zsa_lazy_catchup(start, start - off, anchor, prefixLowest);
                 start -= back; matchLength += back;
                 offset_2 = offset_1; offset_1 = off;
             }
@@ -729,7 +859,18 @@ ZSA_DEV u32 zsa_parse_lazy(ZsaLazyCtx& C, u32 dictLimit, const u8* src, u32 srcS
         nbSeq++;
         anchor = ip = start + matchLength;
         C.lazySkipping = 0;   // :1705-1711
-        // :1735-1745 immediate repcode
+        // :1714-1745 immediate repcode
+        if constexpr (DMS) {
+            while (ZSA_UPTO_LIMIT(ip)) {
+                u32 const mlRep = zsa_lazy_dmsRep(C, (u32)(ip - C.base), offset_2, iendIdx, lane);
+                if (!mlRep) break;
+                { u32 const t = offset_2; offset_2 = offset_1; offset_1 = t; }
+                if (lane == 0) seqOut[nbSeq] = zsa_packseq(0, mlRep - ZSA_MINMATCH, 1);
+                nbSeq++;
+                ip += mlRep;
+                anchor = ip;
+            }
+        } else
         while ((ZSA_UPTO_LIMIT(ip) & (offset_2 > 0)) && (wv_ldg32(ip) == wv_ldg32(ip - offset_2))) {
             matchLength = zsa_lz_count(ip + 4, ip + 4 - offset_2, iend) + 4;
             { u32 const t = offset_2; offset_2 = offset_1; offset_1 = t; }

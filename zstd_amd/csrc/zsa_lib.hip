@@ -109,16 +109,20 @@ ZSA_DEV void zsa_compress_body(ZsaEncShared& S, u32& nextFrame, const ZsaFrameDe
         int const bad = cd ? zsa_resolveCDictUse(&cp, &dictMode, cd->cp, cd->level, cd->dictSize, d.srcSize)
                            : zsa_resolveCParams(&cp, level, d.srcSize, 0, zsa_cpm_noAttachDict);
         // strategies: ZSTD_fast, and ZSTD_dfast .. ZSTD_lazy2 without a dictionary; the tables must fit the workgroup's scratch
-        size_t const tableBytes = bad ? 0 : ((size_t)4 << cp.hlog) + zsa_auxTableBytes(cp.strat, cp.wlog, cp.hlog, cp.clog);
+        // (with a dictionary the finder of greedy .. lazy2 is the CDict's, zstd_compress.c:2294: sized for the larger of the two)
+        size_t const tableBytes = bad ? 0 : ((size_t)4 << cp.hlog) + (cd && cp.strat >= 2 ? ((size_t)4 << (cp.hlog > cp.clog ? cp.hlog : cp.clog))
+                                                                                        : zsa_auxTableBytes(cp.strat, cp.wlog, cp.hlog, cp.clog));
         // (a frame larger than the launch was sized for -- sizes linked on the device -- is refused rather than overrun)
-        bool const unsupported = bad || !(cp.strat == 1 || (cp.strat >= 2 && cp.strat <= 5 && !cd)) || tableBytes > L.htBytes
+        // with a dictionary above ZSTD_fast: the attached dictionary only (payloads up to 16 KiB at ZSTD_dfast, 32 KiB at greedy .. lazy2)
+        bool const unsupported = bad || !(cp.strat == 1 || (cp.strat >= 2 && cp.strat <= 5 && (!cd || (dictMode == zsa_dm_attach && cd->cp.strat == cp.strat)))) || tableBytes > L.htBytes
                               || (d.srcSize > L.blockCap && L.blockCap < ZSA_BLOCKSIZE_MAX);
-        int const fam = cd ? 0 : (cp.strat == 1 ? 2 : (cp.strat == 2 ? 3 : 1));
+        int const fam = cd ? (cp.strat == 1 ? 0 : 4) : (cp.strat == 1 ? 2 : (cp.strat == 2 ? 3 : 1));
         if (unsupported || !((famMask >> fam) & 1)) {
             if (reporter && threadIdx.x == 0) results[f] = ZSA_ERR(ZSA_parameter_unsupported);
         } else if (fam == FAMILY) {
             ZsaEncParams P; P.wlog = cp.wlog; P.hlog = cp.hlog; P.mml = cp.mml; P.tlen = cp.tlen; P.clog = cp.clog; P.strat = cp.strat; P.slog = cp.slog;
-            u64 const r = zsa_encode_frame<FAMILY>(&S, zsa_hashTable, P, d.src, d.srcSize, d.dst, d.dstCapacity, W, FAMILY == 0 ? cd : (const ZsaCDictDev*)nullptr, FAMILY == 0 ? dictMode : (int)zsa_dm_none);
+            bool const withDict = FAMILY == 0 || FAMILY == 4;
+            u64 const r = zsa_encode_frame<FAMILY>(&S, zsa_hashTable, P, d.src, d.srcSize, d.dst, d.dstCapacity, W, withDict ? cd : (const ZsaCDictDev*)nullptr, withDict ? dictMode : (int)zsa_dm_none);
             if (threadIdx.x == 0) results[f] = r;
         }
         __syncthreads();
@@ -143,6 +147,15 @@ zsa_k_compress_dict(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ r
     __shared__ ZsaEncShared S;
     __shared__ u32 nextFrame;
     zsa_compress_body<0>(S, nextFrame, frames, results, nFrames, counter, scratch, L, level, cd, famMask, reporter, prof);
+}
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZSA_ENC_WAVES, ZSA_ENC_WAVES)))
+zsa_k_compress_dict_hi(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
+                       u32* __restrict__ counter, u8* __restrict__ scratch, const ZsaEncLayout L, int level, const ZsaCDictDev* cd, int famMask, int reporter,
+                       u64* __restrict__ prof)
+{   // ZSTD_dfast .. ZSTD_lazy2 with an attached dictionary (BulkProcessor at levels 3 and up)
+    __shared__ ZsaEncShared S;
+    __shared__ u32 nextFrame;
+    zsa_compress_body<4>(S, nextFrame, frames, results, nFrames, counter, scratch, L, level, cd, famMask, reporter, prof);
 }
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZSA_ENC_WAVES, ZSA_ENC_WAVES)))
 zsa_k_compress_dfast(const ZsaFrameDesc* __restrict__ frames, u64* __restrict__ results, u32 nFrames,
@@ -428,7 +441,8 @@ static void zsa_plan_compress(zsa_batch* b, int level, const zsa_CDict* cdict)
         int const bad = cdict ? zsa_resolveCDictUse(&cp, &dictMode, cdict->cp, cdict->level, cdict->dictSize, n)
                               : zsa_resolveCParams(&cp, level, n, 0, zsa_cpm_noAttachDict);
         if (bad) continue;
-        u64 const t = ((u64)4 << cp.hlog) + zsa_auxTableBytes(cp.strat, cp.wlog, cp.hlog, cp.clog);
+        u64 const t = ((u64)4 << cp.hlog) + (cdict && cp.strat >= 2 ? ((u64)4 << (cp.hlog > cp.clog ? cp.hlog : cp.clog))
+                                                                    : zsa_auxTableBytes(cp.strat, cp.wlog, cp.hlog, cp.clog));
         if (t <= ZSA_HT_BYTES && t > b->planHtBytes) b->planHtBytes = t;   // (larger ones are refused per frame by the kernel)
     }
 }
@@ -472,8 +486,10 @@ extern "C" size_t zsa_compress_enqueue(zsa_batch* b, int level, const zsa_CDict*
     // which parser families the level's clevels.h rows can resolve to: a dictionary -> family 0; ZSTD_fast at levels <= 2
     // (level 0 means 3) -> family 2; ZSTD_dfast at levels 2-4 -> family 3; ZSTD_greedy/ZSTD_lazy/ZSTD_lazy2 from level 4 on -> family 1
     int const lv = level == 0 ? 3 : level;
-    bool const fam0 = cdict != nullptr, fam2 = !cdict && lv <= 2, fam3 = !cdict && lv >= 2 && lv <= 4, fam1 = !cdict && lv >= 4;
-    int const famMask = (fam0 ? 1 : 0) | (fam1 ? 2 : 0) | (fam2 ? 4 : 0) | (fam3 ? 8 : 0);
+    // (a CDict's strategy is fixed at its creation; frames that re-resolve their parameters -- 128 KiB and more -- may fall to ZSTD_fast)
+    bool const fam0 = cdict != nullptr, fam4 = cdict != nullptr && cdict->cp.strat >= 2;
+    bool const fam2 = !cdict && lv <= 2, fam3 = !cdict && lv >= 2 && lv <= 4, fam1 = !cdict && lv >= 4;
+    int const famMask = (fam0 ? 1 : 0) | (fam1 ? 2 : 0) | (fam2 ? 4 : 0) | (fam3 ? 8 : 0) | (fam4 ? 16 : 0);
     const ZsaCDictDev* const cd = cdict ? (const ZsaCDictDev*)cdict->d_cd : (const ZsaCDictDev*)nullptr;
     u64* const prof = b->profOn ? b->d_prof : (u64*)nullptr;
     // (same scratch: the launches run one after the other on the stream; the first one reports unsupported frames)
@@ -486,6 +502,11 @@ extern "C" size_t zsa_compress_enqueue(zsa_batch* b, int level, const zsa_CDict*
     if (fam0) {
         hipLaunchKernelGGL(zsa_k_compress_dict, dim3(grid), dim3(64), 0, (hipStream_t)stream,
                            b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter, b->d_encScratch, L, level, cd, famMask, reporter, prof);
+        reporter = 0;
+    }
+    if (fam4) {
+        hipLaunchKernelGGL(zsa_k_compress_dict_hi, dim3(grid), dim3(64), 0, (hipStream_t)stream,
+                           b->d_frames, b->d_results, (u32)b->nFrames, b->d_counter + 8, b->d_encScratch, L, level, cd, famMask, reporter, prof);
         reporter = 0;
     }
     if (fam3) {

@@ -99,7 +99,7 @@ ZSA_HD int zsa_resolveCParams(ZsaCParams* out, int level, u64 srcSizeHint, u64 d
     return 0;
 }
 // How ZSTD_compress_usingCDict brings a digested dictionary into one frame, and with which parameters:
-// zstd_compress.c:5584-5619 (parameters), :5001-5046 (cdict tables vs re-load), :2254-2267 (attach vs copy, ZSTD_fast).
+// zstd_compress.c:5584-5619 (parameters), :5001-5046 (cdict tables vs re-load), :2254-2267 (attach vs copy).
 enum { zsa_dm_none = 0, zsa_dm_attach = 1, zsa_dm_copy = 2, zsa_dm_load = 3 };
 ZSA_HD int zsa_resolveCDictUse(ZsaCParams* out, int* dictMode, const ZsaCParams& cdictCp, int cdictLevel, u64 dictSize, u64 srcSize)
 {
@@ -111,7 +111,9 @@ ZSA_HD int zsa_resolveCDictUse(ZsaCParams* out, int* dictMode, const ZsaCParams&
         if (cp.wlog < limitedSrcLog) cp.wlog = limitedSrcLog;
     }
     if (dictSize > 0 && useCDictParams) {
-        if (srcSize <= 8 * 1024) {
+        // ZSTD_shouldAttachDict: the cut-off of the CDict's strategy (zstd_compress.c:2241-2252)
+        u64 const cutoff = cdictCp.strat <= 1 ? 8 * 1024 : (cdictCp.strat == 2 ? 16 * 1024 : 32 * 1024);
+        if (srcSize <= cutoff) {
             u32 const windowLog = cp.wlog;
             cp = zsa_adjustCParams(cdictCp, srcSize, dictSize, zsa_cpm_attachDict);
             cp.wlog = windowLog;
