@@ -258,8 +258,8 @@ def _oracle():
 
 def kernel_of(level, dictionary):
     """the compress kernel a level resolves to at these frame sizes (clevels.h: ZSTD_fast for levels <= 2, ZSTD_dfast for 3-4, greedy/lazy above)"""
-    if dictionary is not None:
-        return "zsa_k_compress_dict"
+    if dictionary is not None:   # (a CDict's strategy comes from the level and the dictionary's size: ZSTD_fast below level 3)
+        return "zsa_k_compress_dict" if 0 != level < 3 else "zsa_k_compress_dict_hi"
     return "zsa_k_compress" if level < 3 else "zsa_k_compress_dfast" if level < 5 else "zsa_k_compress_lazy"
 
 
@@ -333,6 +333,7 @@ def baseline_configs(zstd_amd, corpus, torch, dev, stream, with_cpu):
     plan = [("C1_json_64KiB_level1", dict(kind="json", fs=65536, n=16384, seed=1234, level=1)),
             ("C2_json_128KiB_level1", dict(kind="json", fs=131072, n=8192, seed=1234, level=1)),
             ("C3_bulk_1KiB_trained_dictionary_level1", dict(kind="json", fs=1024, n=1 << 20, seed=7, level=1, dictionary=trained)),
+            ("bulk_1KiB_trained_dictionary_level5_go_default", dict(kind="json", fs=1024, n=1 << 18, seed=7, level=5, dictionary=trained, steps=1)),
             ("C4_decode_256KiB_level1", dict(kind="log", fs=262144, n=8192, seed=43, level=1, decode_only=True)),
             ("C5_1MiB_chunks_level3_dfast", dict(kind="log", fs=1 << 20, n=4096, seed=44, level=3)),
             ("log_128KiB_level5_go_default", dict(kind="log", fs=131072, n=8192, seed=42, level=5, steps=1))]

@@ -10,7 +10,9 @@
  * and in (128 KB, 256 KB], level 2 in (128 KB, 256 KB]) or ZSTD_greedy / ZSTD_lazy / ZSTD_lazy2 (level 5 -- the default of
  * the reference's Compress(), zstd.go:23 -- at every size; levels 4 to 12 wherever clevels.h selects one of the three),
  * byte-identical to libzstd 1.5.5;
- * dictionary compression (CDict) at the ZSTD_fast levels; decompression of any
+ * dictionary compression (CDict) at every one of these strategies -- at the ZSTD_fast levels for payloads of any size, above
+ * them (a CDict of level 3 and up) for payloads up to the reference's attach cut-off, 16 KiB at ZSTD_dfast and 32 KiB at
+ * ZSTD_greedy .. ZSTD_lazy2 (zstd_compress.c:2241-2252), larger ones answering parameter_unsupported; decompression of any
  * Zstandard frame (concatenated and skippable frames, checksums, dictionaries) except legacy v0.x frames.
  * Anything else returns an error code -- there is no CPU fallback inside this library: every entry point
  * that moves data runs on the GPU and fails loudly when no HIP device is usable.

@@ -22,8 +22,8 @@ import (
 //
 // The engine has no CPU path of its own.  What it does not serve comes back as an error code and is answered by the
 // vendored C right here, so callers of the package see one behaviour:
-//   -40 "Unsupported parameter"      a level/size whose strategy is btlazy2 or above, or a
-//                                    dictionary at a level above the ZSTD_fast ones
+//   -40 "Unsupported parameter"      a level/size whose strategy is btlazy2 or above, or a payload above the
+//                                    attach cut-off (16 / 32 KiB) with a dictionary of level 3 and up
 //   -10 "Unknown frame descriptor"   on a frame that starts with a legacy (v0.1-v0.7) magic number: the vendored
 //                                    build may carry ZSTD_LEGACY_SUPPORT, the engine does not
 //   no usable HIP device             amdUsable is false and the hooks never enter the engine
