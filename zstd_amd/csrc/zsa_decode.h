@@ -765,7 +765,9 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
             // staged bytes, the six fields of a sequence cut from one 64-bit window, and the next sequence's window requested
             // as soon as the three cells tell how many bits this one consumes (the refill then rides on the same LDS round
             // trip as the next cells).  The state it leaves is the one BIT_reloadDStream leaves after every sequence.
-            bool const interior = b.bitsConsumed < 8 && (size_t)(b.ptr - b.start) >= 8u + (64u * 89u + 7u) / 8u + 8u;
+            // (b lives in lane 0: the flag is taken from there)
+            bool const interior = wv_readlane((b.bitsConsumed < 8 && (size_t)(b.ptr - b.start) >= 8u + (64u * 89u + 7u) / 8u + 8u) ? 1u : 0u, 0) != 0;
+#ifdef ZSA_DEC_SERIAL_FIELDS
             if (lane == 0 && interior) {
                 struct __attribute__((packed)) Pk { u64 v; };
                 u32 pOff = (u32)(b.ptr - stageLo), bc = b.bitsConsumed;
@@ -834,7 +836,129 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
 #undef ZSA_TAKE
                 b.ptr = stageLo + pOff; b.bitsConsumed = bc; b.container = W;
                 S->u[ZU_batchN] = (nbSeq == n) && (ZSA_RELOAD(b) < ZB_completed);
-            } else if (lane == 0) {
+            }
+#else
+            // What is serial in a sequence is the walk from one triple of FSE states to the next: three cells, the number of bits
+            // they consume, the three state fields.  So lane 0 does just that per sequence and leaves a RECORD -- the 64-bit window
+            // at the sequence's first bit and the three states it was decoded in -- and the values are cut from the records by all
+            // lanes afterwards, one sequence per lane: extra bits, lengths, the offset or the repeat-offset code.  The repeat-offset
+            // history is the other chain; it is replayed over the repeat codes only (new offsets between two of them are applied in
+            // one step), in uniform control flow.
+            if (lane == 0 && interior) {
+                struct __attribute__((packed)) Pk { u64 v; };
+                u32 pOff = (u32)(b.ptr - stageLo), bc = b.bitsConsumed;
+                u64 W = ((const Pk*)(S->bits + pOff))->v;
+#define ZSA_TAKE(v, nb) do { v = (u32)((X >> 1) >> (63u - (nb))); X <<= (nb); } while (0)
+                for (u32 i = 0; i < n; i++) {
+                    ZsaSeqCell const ll = S->ll[stLL], ml = S->ml[stML], of = S->of[stOF];
+                    u32 const llH = (u32)(ll >> 32), mlH = (u32)(ml >> 32), ofH = (u32)(of >> 32);
+                    // the three high words added as they are: byte 2 = extra bits of the sequence, byte 3 = state bits (the low
+                    // halves, three state bases below 512 each, cannot carry into them)
+                    u32 const sum = llH + mlH + ofH;
+                    u32 const E = (sum >> 16) & 0xFF, T = sum >> 24;
+                    u32 const llS = llH >> 24, mlS = mlH >> 24, ofS = ofH >> 24;
+                    u64 const X0 = W << bc;
+                    u32 pk = stLL | (stML << 9) | (stOF << 18);
+                    u32 sl, sm, so;
+                    u32 const used = bc + E + T;
+                    if (E + T <= 32) {   // the usual case: all six fields lie in the top 32 bits of the window
+                        u32 const top = (u32)(X0 >> 32);
+                        u32 const at4 = 32u - E - llS, at5 = at4 - mlS, at6 = at5 - ofS;
+                        pOff -= used >> 3; bc = used & 7;
+                        W = ((const Pk*)(S->bits + pOff))->v;
+                        sl = wv_bfe(top, at4, llS); sm = wv_bfe(top, at5, mlS); so = wv_bfe(top, at6, ofS);
+                    } else if (used <= 64) {
+                        u64 X = X0 << E;
+                        pOff -= used >> 3; bc = used & 7;
+                        W = ((const Pk*)(S->bits + pOff))->v;
+                        ZSA_TAKE(sl, llS); ZSA_TAKE(sm, mlS); ZSA_TAKE(so, ofS);
+                    } else {   // more than a window holds: refill after the offset and match-length bits (<= 7 + 31 + 16); the
+                               // literal-length bits are then cut here and travel beside the record
+                        u32 const ofBits = (ofH >> 16) & 0xFF, mlBits = (mlH >> 16) & 0xFF, llBits = (llH >> 16) & 0xFF;
+                        u32 llx;
+                        {   u32 const u1 = bc + ofBits + mlBits;
+                            pOff -= u1 >> 3; bc = u1 & 7;
+                            W = ((const Pk*)(S->bits + pOff))->v;
+                        }
+                        u64 X = W << bc;
+                        ZSA_TAKE(llx, llBits); ZSA_TAKE(sl, llS); ZSA_TAKE(sm, mlS); ZSA_TAKE(so, ofS);
+                        {   u32 const u2 = bc + llBits + llS + mlS + ofS;
+                            pOff -= u2 >> 3; bc = u2 & 7;
+                            W = ((const Pk*)(S->bits + pOff))->v;
+                        }
+                        S->mStart[i] = llx; pk |= 0x80000000u;
+                    }
+                    S->seqLL[i] = (u32)X0; S->seqML[i] = (u32)(X0 >> 32); S->seqOF[i] = pk;
+                    stLL = (llH & 0xFFFF) + sl; stML = (mlH & 0xFFFF) + sm; stOF = (ofH & 0xFFFF) + so;
+                }
+                b.ptr = stageLo + pOff; b.bitsConsumed = bc; b.container = W;
+                S->u[ZU_batchN] = (nbSeq == n) && (ZSA_RELOAD(b) < ZB_completed);
+            }
+            if (interior) {
+                wv_lds_fence();
+                bool const act = (u32)lane < n;
+                u32 vLL = 0, vML = 0, vOF = 1, rc = 0;
+                bool isN = false;
+                if (act) {
+                    u32 const pk = S->seqOF[lane];
+                    u64 X = ((u64)S->seqML[lane] << 32) | S->seqLL[lane];
+                    ZsaSeqCell const ll = S->ll[pk & 511u], ml = S->ml[(pk >> 9) & 511u], of = S->of[(pk >> 18) & 255u];
+                    u32 const ofBits = (u32)(of >> 48) & 0xFF, mlBits = (u32)(ml >> 48) & 0xFF, llBits = (u32)(ll >> 48) & 0xFF;
+                    u32 ofx, mlx, llx;
+                    ZSA_TAKE(ofx, ofBits); ZSA_TAKE(mlx, mlBits); ZSA_TAKE(llx, llBits);
+                    if (pk >> 31) llx = S->mStart[lane];
+                    vLL = (u32)ll + llx; vML = (u32)ml + mlx;
+                    // zstd_decompress_block.c:1236-1269: a new offset, or a repeat code 0 .. 3 (0: the last offset again, the history
+                    // stays; 1 / 2: the one before / two before moves to the front; 3: the last offset minus one)
+                    u32 const ll0 = ((u32)ll == 0);
+                    if (ofBits > 1) { isN = true; vOF = (u32)of + ofx; }
+                    else rc = ofBits == 0 ? ll0 : (u32)of + ll0 + ofx;
+                }
+#undef ZSA_TAKE
+                u64 const newMask = wv_ballot(act && isN), repMask = wv_ballot(act && !isN && rc != 0);
+                u32 q0 = wv_readlane(r0, 0), q1 = wv_readlane(r1, 0), q2 = wv_readlane(r2, 0);
+                u32 const first0 = q0;
+                u64 rm = repMask;
+                u32 pos = 0;
+                for (;;) {
+                    u32 const j = rm ? (u32)__builtin_ctzll(rm) : n;
+                    // the new offsets of [pos, j): the last three of them are what is left in the history
+                    u64 ns = pos < 64 ? (newMask >> pos) << pos : 0;
+                    if (j < 64) ns &= ((u64)1 << j) - 1u;
+                    if (ns) {
+                        u32 const i1 = 63u - (u32)__builtin_clzll(ns); ns &= ~((u64)1 << i1);
+                        u32 const a1 = wv_readlane(vOF, (int)i1);
+                        if (ns) {
+                            u32 const i2 = 63u - (u32)__builtin_clzll(ns); ns &= ~((u64)1 << i2);
+                            u32 const a2 = wv_readlane(vOF, (int)i2);
+                            if (ns) { u32 const i3 = 63u - (u32)__builtin_clzll(ns); q2 = wv_readlane(vOF, (int)i3); }
+                            else q2 = q0;
+                            q1 = a2;
+                        } else { q2 = q1; q1 = q0; }
+                        q0 = a1;
+                    }
+                    if (!rm) break;
+                    u32 const cj = wv_readlane(rc, (int)j);
+                    u32 temp = cj == 3 ? q0 - 1u : (cj == 1 ? q1 : q2);
+                    temp += !temp;
+                    if (cj != 1) q2 = q1;
+                    q1 = q0; q0 = temp;
+                    if ((u32)lane == j) vOF = temp;
+                    pos = j + 1; rm &= rm - 1;
+                }
+                {   // repeat code 0: the offset of the nearest earlier sequence that set one, else the one the batch began with
+                    u64 const setters = newMask | repMask;
+                    u64 const below = setters & (((u64)1 << lane) - 1u);
+                    u32 const from = below ? 63u - (u32)__builtin_clzll(below) : 0u;
+                    u32 const prev = wv_shfl(vOF, (int)from);
+                    if (act && !isN && rc == 0) vOF = below ? prev : first0;
+                }
+                if (act) { S->seqLL[lane] = vLL; S->seqML[lane] = vML; S->seqOF[lane] = vOF; }
+                r0 = q0; r1 = q1; r2 = q2;   // (every lane's copy: lane 0's is the one the serial reader below carries on with)
+                wv_lds_fence();
+            }
+#endif
+            if (lane == 0 && !interior) {
                 for (u32 i = 0; i < n; i++) {
                     ZsaSeqCell const ll = S->ll[stLL], ml = S->ml[stML], of = S->of[stOF];
                     u32 matchLength = (u32)ml, litLength = (u32)ll, offset;
