@@ -840,7 +840,8 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
 #else
             // What is serial in a sequence is the walk from one triple of FSE states to the next: three cells, the number of bits
             // they consume, the three state fields.  So lane 0 does just that per sequence and leaves a RECORD -- the 64-bit window
-            // at the sequence's first bit and the three states it was decoded in -- and the values are cut from the records by all
+            // at the sequence's first bit and the three states it was decoded in (four words, in the batch arrays the execution
+            // stage fills later) -- and the values are cut from the records by all
             // lanes afterwards, one sequence per lane: extra bits, lengths, the offset or the repeat-offset code.  The repeat-offset
             // history is the other chain; it is replayed over the repeat codes only (new offsets between two of them are applied in
             // one step), in uniform control flow.
@@ -858,16 +859,17 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                     u32 const E = (sum >> 16) & 0xFF, T = sum >> 24;
                     u32 const llS = llH >> 24, mlS = mlH >> 24, ofS = ofH >> 24;
                     u64 const X0 = W << bc;
-                    u32 pk = stLL | (stML << 9) | (stOF << 18);
+                    u32 const pk = stLL | (stML << 16);
+                    u32 pk2 = stOF;
                     u32 sl, sm, so;
                     u32 const used = bc + E + T;
-                    if (E + T <= 32) {   // the usual case: all six fields lie in the top 32 bits of the window
+                    if (wv_single_lane_b(E + T <= 32)) {   // the usual case: all six fields lie in the top 32 bits of the window
                         u32 const top = (u32)(X0 >> 32);
                         u32 const at4 = 32u - E - llS, at5 = at4 - mlS, at6 = at5 - ofS;
                         pOff -= used >> 3; bc = used & 7;
                         W = ((const Pk*)(S->bits + pOff))->v;
                         sl = wv_bfe(top, at4, llS); sm = wv_bfe(top, at5, mlS); so = wv_bfe(top, at6, ofS);
-                    } else if (used <= 64) {
+                    } else if (wv_single_lane_b(used <= 64)) {
                         u64 X = X0 << E;
                         pOff -= used >> 3; bc = used & 7;
                         W = ((const Pk*)(S->bits + pOff))->v;
@@ -886,9 +888,9 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                             pOff -= u2 >> 3; bc = u2 & 7;
                             W = ((const Pk*)(S->bits + pOff))->v;
                         }
-                        S->mStart[i] = llx; pk |= 0x80000000u;
+                        S->mStart[i] = llx; pk2 |= 0x80000000u;
                     }
-                    S->seqLL[i] = (u32)X0; S->seqML[i] = (u32)(X0 >> 32); S->seqOF[i] = pk;
+                    S->seqLL[i] = (u32)X0; S->seqML[i] = (u32)(X0 >> 32); S->seqOF[i] = pk; S->outStart[i] = pk2;
                     stLL = (llH & 0xFFFF) + sl; stML = (mlH & 0xFFFF) + sm; stOF = (ofH & 0xFFFF) + so;
                 }
                 b.ptr = stageLo + pOff; b.bitsConsumed = bc; b.container = W;
@@ -900,13 +902,13 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                 u32 vLL = 0, vML = 0, vOF = 1, rc = 0;
                 bool isN = false;
                 if (act) {
-                    u32 const pk = S->seqOF[lane];
+                    u32 const pk = S->seqOF[lane], pk2 = S->outStart[lane];
                     u64 X = ((u64)S->seqML[lane] << 32) | S->seqLL[lane];
-                    ZsaSeqCell const ll = S->ll[pk & 511u], ml = S->ml[(pk >> 9) & 511u], of = S->of[(pk >> 18) & 255u];
+                    ZsaSeqCell const ll = S->ll[pk & 0xFFFFu], ml = S->ml[pk >> 16], of = S->of[pk2 & 0xFFFFu];
                     u32 const ofBits = (u32)(of >> 48) & 0xFF, mlBits = (u32)(ml >> 48) & 0xFF, llBits = (u32)(ll >> 48) & 0xFF;
                     u32 ofx, mlx, llx;
                     ZSA_TAKE(ofx, ofBits); ZSA_TAKE(mlx, mlBits); ZSA_TAKE(llx, llBits);
-                    if (pk >> 31) llx = S->mStart[lane];
+                    if (pk2 >> 31) llx = S->mStart[lane];
                     vLL = (u32)ll + llx; vML = (u32)ml + mlx;
                     // zstd_decompress_block.c:1236-1269: a new offset, or a repeat code 0 .. 3 (0: the last offset again, the history
                     // stays; 1 / 2: the one before / two before moves to the front; 3: the last offset minus one)
