@@ -124,22 +124,25 @@ typedef struct {
 
 typedef struct { zo_entropy entropy; u32 rep[3]; } zo_cblockstate;
 
-/* ---- LSB-first bit writer (bitstream.h:154-241; flush points never change the bytes) ---- */
-typedef struct { u8* start; u8* p; u64 acc; u32 nb; } zo_bitw;
-static inline void zo_bw_init(zo_bitw* w, void* dst) { w->start = w->p = (u8*)dst; w->acc = 0; w->nb = 0; }
+/* ---- LSB-first bit writer (bitstream.h:154-241; flush points never change the bytes) ----
+ * `end` bounds the output like the reference's endPtr does (bitstream.h:203-212, huf_compress.c:885-950): bytes beyond it are
+ * dropped and the stream closes as 0, "does not fit" -- what the callers turn into raw literals / a raw block. */
+typedef struct { u8* start; u8* p; u8* end; u64 acc; u32 nb; int over; } zo_bitw;
+static inline void zo_bw_init(zo_bitw* w, void* dst, void* end) { w->start = w->p = (u8*)dst; w->end = (u8*)end; w->acc = 0; w->nb = 0; w->over = 0; }
+static inline void zo_bw_put(zo_bitw* w, u8 b) { if (w->end && w->p >= w->end) w->over = 1; else *w->p++ = b; }
 static inline void zo_bw_add(zo_bitw* w, u64 value, u32 nbBits)
 {   /* BIT_addBits masks the value (bitstream.h:176-187) */
     if (nbBits == 0) return;
     value &= (nbBits >= 64) ? ~(u64)0 : (((u64)1 << nbBits) - 1);
     w->acc |= value << w->nb;
     w->nb += nbBits;
-    while (w->nb >= 8) { *w->p++ = (u8)w->acc; w->acc >>= 8; w->nb -= 8; }
+    while (w->nb >= 8) { zo_bw_put(w, (u8)w->acc); w->acc >>= 8; w->nb -= 8; }
 }
 static inline size_t zo_bw_close(zo_bitw* w)
-{   /* BIT_closeCStream: end mark '1' then zero padding (bitstream.h:229-241) */
+{   /* BIT_closeCStream: end mark '1' then zero padding (bitstream.h:229-241); 0 when the stream did not fit */
     zo_bw_add(w, 1, 1);
-    if (w->nb) { *w->p++ = (u8)w->acc; w->acc = 0; w->nb = 0; }
-    return (size_t)(w->p - w->start);
+    if (w->nb) { zo_bw_put(w, (u8)w->acc); w->acc = 0; w->nb = 0; }
+    return w->over ? 0 : (size_t)(w->p - w->start);
 }
 
 /* ---- compression parameters ---- */

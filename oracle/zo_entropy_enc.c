@@ -476,7 +476,7 @@ static size_t zo_fse_compressWeightsStream(u8* dst, const u8* src, size_t srcSiz
     zo_bitw w;
     zo_fse_cstate s1, s2;
     if (srcSize <= 2) return 0;
-    zo_bw_init(&w, dst);
+    zo_bw_init(&w, dst, NULL);
     if (srcSize & 1) {
         zo_fse_initCState2(&s1, ct->nextState, ct->deltaFindState, ct->deltaNbBits, ct->tableLog, *--ip);
         zo_fse_initCState2(&s2, ct->nextState, ct->deltaFindState, ct->deltaNbBits, ct->tableLog, *--ip);
@@ -543,11 +543,14 @@ static size_t zo_huf_writeCTable(u8* dst, size_t maxDstSize, const zo_huf_ctable
     return ((maxSV + 1) / 2) + 1;
 }
 /* huf_compress.c:1023-1086 + :941-950: one stream, symbols last->first, end mark */
+/* end of the block's output buffer while a block is entropy-coded (set by zo_entropyCompressSeqStore): the Huffman streams and
+ * the sequence bitstream stop there, as the reference's do (huf_compress.c:1040-1048, zstd_compress_sequences.c:303-306) */
+static __thread u8* zo_block_oend;
 static size_t zo_huf_encode1X(u8* dst, const u8* src, size_t srcSize, const zo_huf_ctable* ct)
 {
     zo_bitw w;
     size_t n = srcSize;
-    zo_bw_init(&w, dst);
+    zo_bw_init(&w, dst, zo_block_oend);
     while (n > 0) { u8 const s = src[--n]; zo_bw_add(&w, ct->val[s], ct->nbBits[s]); }
     return zo_bw_close(&w);
 }
@@ -884,7 +887,7 @@ static size_t zo_encodeSequences(u8* dst, const zo_seq_ctable* ctML, const u8* m
     zo_bitw w;
     zo_fse_cstate sML, sOF, sLL;
     size_t n;
-    zo_bw_init(&w, dst);
+    zo_bw_init(&w, dst, zo_block_oend);
     zo_fse_initCState2(&sML, ctML->nextState, ctML->deltaFindState, ctML->deltaNbBits, ctML->tableLog, mlCode[nbSeq - 1]);
     zo_fse_initCState2(&sOF, ctOF->nextState, ctOF->deltaFindState, ctOF->deltaNbBits, ctOF->tableLog, ofCode[nbSeq - 1]);
     zo_fse_initCState2(&sLL, ctLL->nextState, ctLL->deltaFindState, ctLL->deltaNbBits, ctLL->tableLog, llCode[nbSeq - 1]);
@@ -922,6 +925,7 @@ size_t zo_entropyCompressSeqStore(const zo_seqstore* ss, const zo_entropy* prev,
     size_t lastCountSize = 0;
     u32 count[ZO_MaxSeq + 1];
 
+    zo_block_oend = oend;
     {   size_t const litSize = ss->litSize;
         int const suspect = (nbSeq == 0) || (litSize / nbSeq >= 20);
         size_t const c = zo_compressLiterals(op, dstCapacity, ss->lit, litSize, prev, next, literalsDisabled, suspect, strategy);
@@ -980,6 +984,9 @@ size_t zo_entropyCompressSeqStore(const zo_seqstore* ss, const zo_entropy* prev,
         *seqHead = (u8)((LLtype << 6) + (OFtype << 4) + (MLtype << 2));
     }
     {   size_t const bitstreamSize = zo_encodeSequences(op, &next->ml, mlCode, &next->of, ofCode, &next->ll, llCode, ss->seq, nbSeq);
+        /* :2929-2932 + :2961-2966: a bitstream that does not fit (dstSize_tooSmall) makes the block a raw one when the block
+         * itself fits the buffer, else it is the frame's error */
+        if (bitstreamSize == 0) return srcSize <= dstCapacity ? 0 : ZO_ERR(dstSize_tooSmall);
         op += bitstreamSize;
         if (lastCountSize && (lastCountSize + bitstreamSize) < 4) return 0;   /* :2938-2944 */
     }

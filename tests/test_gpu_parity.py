@@ -300,6 +300,39 @@ def test_bulk_processor_seeded_payloads_above_fast(z, oracle):
     assert compared > 350
 
 
+def test_streams_longer_than_their_input_stay_inside_the_frame(z, oracle):
+    """A Huffman table taken over from a dictionary (up to 1 KiB of literals it is used without an estimate,
+    huf_compress.c:1336-1341) can code literals a third LONGER than they are; the reference's stream writers stop at the end of
+    their buffer and the literals go out raw.  The device writers must stop as well: every frame sits in a slot of exactly its
+    bound, with guard bytes behind it that have to survive, and equals the oracle's frame."""
+    import torch
+    from test_oracle_dict import load_dict_cases
+    dicts = load_dict_cases()[0]
+    rnd = random.Random(41)
+    FS, N = 1000, 256
+    payloads = [rnd.randbytes(FS) if i % 3 == 0 else bytes(rnd.randrange(160, 256) for _ in range(FS)) if i % 3 == 1
+                else (dicts["trained_json_8k"][20 * i:20 * i + 150] + rnd.randbytes(FS))[:FS] for i in range(N)]
+    assert all(len(p) == FS for p in payloads)
+    src = torch.frombuffer(bytearray(b"".join(payloads)), dtype=torch.uint8).cuda()
+    bound = z.CompressBound(FS)
+    stride = bound + 512
+    for dn in ("trained_json_8k", "trained_log_4k", "ref_test_dict"):
+        for level in (1, 3, 5):
+            bp = z.NewBulkProcessor(dicts[dn], level)
+            cbuf = torch.full((N * stride,), 0xA5, dtype=torch.uint8, device="cuda")
+            enc = z.DeviceBatch(N)
+            enc.set_frames_strided(N, src.data_ptr(), FS, None, cbuf.data_ptr(), stride, bound)
+            enc.compress(level, bp.cDict)
+            cs = enc.results()
+            ch = cbuf.cpu().numpy()
+            ocd = oracle.cdict(dicts[dn], level)
+            for i in range(N):
+                assert 0 < cs[i] <= bound, (dn, level, i, cs[i])
+                assert bool((ch[i * stride + bound:(i + 1) * stride] == 0xA5).all()), (dn, level, i, "bytes behind the frame's capacity were written")
+                assert ch[i * stride:i * stride + cs[i]].tobytes() == oracle.compress_cdict(payloads[i], ocd), (dn, level, i)
+            oracle.free_cdict(ocd)
+
+
 def test_bulk_processor_seeded_payloads(z, oracle):
     """Seeded payloads of 1 B .. 300 KB against every fixture dictionary, at the two ZSTD_fast levels the engine serves with a
     dictionary: attached (<= 8 KiB), external segment (above; multi-block payloads, steps that have grown over incompressible

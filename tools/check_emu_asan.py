@@ -52,6 +52,10 @@ if "nodict" not in sys.argv:
         d = dicts[dn]
         pl = [corpus.frames("json", n, 1, 50 + i)[0] for i, n in enumerate([1, 9, 300, 1024, 8192, 16384, 30000])]
         pl += [(d[-min(len(d), 700):] + rnd.randbytes(20)) * 12, d[:min(len(d), 5000)], bytes(3000), rnd.randbytes(2000)]
+        # literals that a dictionary's Huffman table makes LONGER than they are (taken over without an estimate up to 1 KiB of
+        # literals, huf_compress.c:1336-1341): the stream writers must stop at the frame's end
+        pl += [rnd.randbytes(300), rnd.randbytes(700), rnd.randbytes(1000), bytes(rnd.randrange(128, 256) for _ in range(900)),
+               d[:min(len(d), 200)] + bytes(rnd.randrange(200, 256) for _ in range(800))]
         for level in (1, 3, 4, 5, 7, 8):
             cd = emu.emu_create_cdict(d, len(d), level)
             ocd = orc.cdict(d, level)

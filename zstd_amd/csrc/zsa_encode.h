@@ -680,7 +680,8 @@ ZSA_DEV u32 zsa_huf_estimate(const ZsaHufCT* ct, const u32* count, u32 maxSV, in
 }
 // The same stream written by all lanes: 256 symbols per step (4 per lane, last symbol first), prefix sum of the code
 // lengths, LDS atomic-or packing, whole words flushed together.  Returns the stream size (uniform).
-ZSA_DEV u32 zsa_huf_encode_wave(ZsaEncShared* S, u8* dst, const u8* src, u32 srcSize, const ZsaHufCT* ct, int lane);
+#define ZSA_HUF_NOFIT 0xFFFFFFFFu
+ZSA_DEV u32 zsa_huf_encode_wave(ZsaEncShared* S, u8* dst, const u8* src, u32 srcSize, const ZsaHufCT* ct, u32 cap, int lane);
 
 // all-lane histogram of bytes into S->count[0..255] (hist.c:30-165): exact counts
 ZSA_DEV void zsa_hist_bytes(ZsaEncShared* S, const u8* src, u32 n, int lane)
@@ -691,7 +692,11 @@ ZSA_DEV void zsa_hist_bytes(ZsaEncShared* S, const u8* src, u32 n, int lane)
     wv_sync();
 }
 
-ZSA_DEV u32 zsa_huf_encode_wave(ZsaEncShared* S, u8* dst, const u8* src, u32 srcSize, const ZsaHufCT* ct, int lane)
+// One Huffman stream (huf_compress.c:1023-1086), at most `cap` bytes: a stream that would be longer is given up as soon as that
+// is known and ZSA_HUF_NOFIT returned -- the reference's writer stops at the end of its buffer the same way (:885-950) and the
+// literals then go out raw; with a table taken over from a dictionary a stream can be a third LONGER than its input, which
+// nothing else keeps inside the frame's destination.
+ZSA_DEV u32 zsa_huf_encode_wave(ZsaEncShared* S, u8* dst, const u8* src, u32 srcSize, const ZsaHufCT* ct, u32 cap, int lane)
 {
     ZsaSeqEncScratch* const E = &S->enc;
     for (u32 i = (u32)lane; i < 256; i += ZSA_WAVE) E->bitbuf[i] = 0;
@@ -722,6 +727,7 @@ ZSA_DEV u32 zsa_huf_encode_wave(ZsaEncShared* S, u8* dst, const u8* src, u32 src
         }
         totalBits += chunkBits;
         wv_lds_fence();
+        if (((totalBits + 8) >> 3) > cap) return ZSA_HUF_NOFIT;   // (with the end mark; uniform; whole words only are flushed below: never past cap)
         {   u32 const done = (totalBits >> 5) - flushedWords;
             for (u32 i = (u32)lane; i < done; i += ZSA_WAVE) { u32 const wv_ = E->bitbuf[i]; __builtin_memcpy(dst + 4 * (flushedWords + i), &wv_, 4); }
             u32 const carry = E->bitbuf[done];
@@ -843,19 +849,23 @@ ZSA_DEV u32 zsa_compressLiterals(ZsaEncShared* S, u8* dst, const u8* lit, u32 li
         const ZsaHufCT* const ct = (decision == 2) ? &S->hufPrev : &S->hufNext;
         u8* const op = ostart + hSize;
         u32 total = 0;
+        // a literal section of litSize bytes or more is never kept (:1192-1207, zstd_compress_literals.c:186-191): that is the budget
+        u32 const budget = litSize > hSize ? litSize - hSize : 0;
         if (singleStream) {
-            total = zsa_huf_encode_wave(S, op, lit, litSize, ct, lane);
+            total = zsa_huf_encode_wave(S, op, lit, litSize, ct, budget, lane);
+            if (total == ZSA_HUF_NOFIT) total = 0;
         } else if (litSize >= 12) {
             // huf_compress.c:1135-1183: 6-byte jump table, 4 segments of (n+3)/4, written one after the other
             u32 const segmentSize = (litSize + 3) / 4;
-            u32 c[4], at = 6;
+            u32 c[4] = { ZSA_HUF_NOFIT, ZSA_HUF_NOFIT, ZSA_HUF_NOFIT, ZSA_HUF_NOFIT }, at = 6;
             for (u32 k = 0; k < 4; k++) {
                 u32 const beg = k * segmentSize;
                 u32 const len = (k == 3) ? litSize - 3 * segmentSize : segmentSize;
-                c[k] = zsa_huf_encode_wave(S, op + at, lit + beg, len, ct, lane);
+                c[k] = zsa_huf_encode_wave(S, op + at, lit + beg, len, ct, budget > at ? budget - at : 0, lane);
+                if (c[k] == ZSA_HUF_NOFIT) break;
                 at += c[k];
             }
-            if (c[0] > 65535 || c[1] > 65535 || c[2] > 65535 || c[3] > 65535) total = 0;
+            if (c[0] > 65535 || c[1] > 65535 || c[2] > 65535 || c[3] > 65535) total = 0;   // (includes ZSA_HUF_NOFIT)
             else {
                 if (lane == 0) { zsa_st16(op, c[0]); zsa_st16(op + 2, c[1]); zsa_st16(op + 4, c[2]); }
                 total = at;
@@ -1206,6 +1216,10 @@ ZSA_DEV u32 zsa_entropyCompress(ZsaEncShared* S, const u64* seq, u32 nbSeq, cons
                 }
                 totalBits += chunkBits;
                 wv_lds_fence();
+                // a block body of srcSize bytes or more is never kept (:2975-2979; the reference's own writer stops at the end of
+                // its buffer and the block then goes out raw, :2929-2932): give up as soon as that is known -- with tables taken
+                // over from a dictionary the bitstream of many short sequences can outgrow the block
+                if ((u32)(op - dst) + ((totalBits + 7) >> 3) > srcSize) return 0;
                 {   // flush whole words, carry the partial one
                     u32 const done = (totalBits >> 5) - flushedWords;
                     for (u32 i = (u32)lane; i < done; i += ZSA_WAVE) { u32 const wv_ = E->bitbuf[i]; __builtin_memcpy(op + 4 * (flushedWords + i), &wv_, 4); }
