@@ -17,6 +17,7 @@
 #define ZSA_HD     static inline
 #define ZSA_SHARED static
 #define ZSA_WAVE   64
+#define ZSA_LDS
 
 struct ZsaEmu {
     ucontext_t main_ctx;

@@ -701,17 +701,29 @@ ZSA_DEV u32 zsa_huf_encode_wave(ZsaEncShared* S, u8* dst, const u8* src, u32 src
     ZsaSeqEncScratch* const E = &S->enc;
     for (u32 i = (u32)lane; i < 256; i += ZSA_WAVE) E->bitbuf[i] = 0;
     u32 totalBits = 0, flushedWords = 0;
+    // (the table is one of two in LDS, chosen at run time: as LDS pointers; the literals lie in global scratch: a lane's four
+    // symbols are one 4-byte load)
+    ZSA_LDS const u8* const nbT = (ZSA_LDS const u8*)ct->nbBits;
+    ZSA_LDS const u16* const valT = (ZSA_LDS const u16*)ct->val;
     wv_lds_fence();
     for (u32 tBase = 0; tBase < srcSize; tBase += 4 * ZSA_WAVE) {
         u64 blob = 0; u32 len = 0;
         u32 const t0 = tBase + 4u * (u32)lane;
+        if (t0 + 4 <= srcSize) {
+            u32 const w4 = wv_ldg32(src + (srcSize - 4 - t0));   // symbols t0 .. t0 + 3 are its bytes 3 .. 0
+#pragma unroll
+            for (u32 k = 0; k < 4; k++) {
+                u32 const sym = (w4 >> (8u * (3u - k))) & 0xFFu;
+                blob |= (u64)valT[sym] << len;
+                len += nbT[sym];
+            }
+        } else
         for (u32 k = 0; k < 4; k++) {
             u32 const t = t0 + k;
             if (t < srcSize) {
-                u32 const sym = src[srcSize - 1 - t];
-                u32 const nb = ct->nbBits[sym];
-                blob |= (u64)ct->val[sym] << len;
-                len += nb;
+                u32 const sym = wv_ldg8(src + (srcSize - 1 - t));
+                blob |= (u64)valT[sym] << len;
+                len += nbT[sym];
             }
         }
         u32 const incl = wv_scan_incl(len);
@@ -729,7 +741,7 @@ ZSA_DEV u32 zsa_huf_encode_wave(ZsaEncShared* S, u8* dst, const u8* src, u32 src
         wv_lds_fence();
         if (((totalBits + 8) >> 3) > cap) return ZSA_HUF_NOFIT;   // (with the end mark; uniform; whole words only are flushed below: never past cap)
         {   u32 const done = (totalBits >> 5) - flushedWords;
-            for (u32 i = (u32)lane; i < done; i += ZSA_WAVE) { u32 const wv_ = E->bitbuf[i]; __builtin_memcpy(dst + 4 * (flushedWords + i), &wv_, 4); }
+            for (u32 i = (u32)lane; i < done; i += ZSA_WAVE) wv_stg32(dst + 4 * (flushedWords + i), E->bitbuf[i]);
             u32 const carry = E->bitbuf[done];
             wv_lds_fence();
             for (u32 i = (u32)lane; i <= done + 4 && i < 256; i += ZSA_WAVE) E->bitbuf[i] = 0;
@@ -744,7 +756,7 @@ ZSA_DEV u32 zsa_huf_encode_wave(ZsaEncShared* S, u8* dst, const u8* src, u32 src
     totalBits += 1;
     wv_lds_fence();
     u32 const totalBytes = (totalBits + 7) >> 3;
-    for (u32 i = flushedWords * 4 + (u32)lane; i < totalBytes; i += ZSA_WAVE) dst[i] = ((const u8*)E->bitbuf)[i - flushedWords * 4];
+    for (u32 i = flushedWords * 4 + (u32)lane; i < totalBytes; i += ZSA_WAVE) wv_stg8(dst + i, ((const u8*)E->bitbuf)[i - flushedWords * 4]);
     wv_lds_fence();
     return totalBytes;
 }
@@ -1156,6 +1168,15 @@ ZSA_DEV u32 zsa_entropyCompress(ZsaEncShared* S, const u64* seq, u32 nbSeq, cons
             const ZsaFseCT* const myCT = lane == 0 ? &S->of : (lane == 1 ? &S->ml : &S->ll);
             ZsaFseCState st; st.value = 0; st.next = myCT->nextState; st.dfs = myCT->dfs; st.dnb = myCT->dnb; st.stateLog = myCT->tableLog;
             u32 totalBits = 0, flushedWords = 0;
+            // the chain lanes' tables and batch arrays as LDS pointers (one table per lane: as generic pointers every access
+            // of the chain paid a 64-bit addition and a null check, the last one of four a flat load)
+            int const cl = lane < 3 ? lane : 0;
+            ZSA_LDS const u8*  const cCodes = (ZSA_LDS const u8*)E->code[cl];
+            ZSA_LDS const u16* const cNext = (ZSA_LDS const u16*)myCT->nextState;
+            ZSA_LDS const s32* const cDfs = (ZSA_LDS const s32*)myCT->dfs;
+            ZSA_LDS const u32* const cDnb = (ZSA_LDS const u32*)myCT->dnb;
+            ZSA_LDS u16* const cBits = (ZSA_LDS u16*)E->stBits[cl];
+            ZSA_LDS u8*  const cNb = (ZSA_LDS u8*)E->stNb[cl];
             wv_lds_fence();
             for (u32 tBase = 0; tBase < nbSeq; tBase += ZSA_WAVE) {
                 u32 const cnt = (nbSeq - tBase) < ZSA_WAVE ? (nbSeq - tBase) : ZSA_WAVE;
@@ -1172,23 +1193,25 @@ ZSA_DEV u32 zsa_entropyCompress(ZsaEncShared* S, const u64* seq, u32 nbSeq, cons
                     // One step = one table read that depends on the step before it.  What a step needs besides the state -- the
                     // symbol's two transform words -- depends on the symbol only, so it is fetched four steps at a time ahead
                     // of the chain: a step then costs one LDS round trip instead of four.
-                    const u8* const codes = E->code[lane];
                     u32 j = 0;
-#define ZSA_CHAIN_STEP(dnbv, dfsv, jj) do { u32 const nbBitsOut = (st.value + (dnbv)) >> 16;                                   \
-                        E->stBits[lane][jj] = (u16)(st.value & ((1u << nbBitsOut) - 1u)); E->stNb[lane][jj] = (u8)nbBitsOut;      \
-                        st.value = st.next[(s32)(st.value >> nbBitsOut) + (dfsv)]; } while (0)
+                    u32 value = st.value;
+#define ZSA_CHAIN_STEP(dnbv, dfsv, jj) do { u32 const nbBitsOut = (value + (dnbv)) >> 16;                                   \
+                        cBits[jj] = (u16)(value & ((1u << nbBitsOut) - 1u)); cNb[jj] = (u8)nbBitsOut;      \
+                        value = cNext[(s32)(value >> nbBitsOut) + (dfsv)]; } while (0)
                     if (tBase == 0) {   // FSE_initCState2 with the last sequence's code
-                        zsa_fse_initCState2(st, st.next, st.dfs, st.dnb, st.stateLog, codes[0]);
-                        E->stBits[lane][0] = 0; E->stNb[lane][0] = 0;
+                        zsa_fse_initCState2(st, st.next, st.dfs, st.dnb, st.stateLog, cCodes[0]);
+                        value = st.value;
+                        cBits[0] = 0; cNb[0] = 0;
                         j = 1;
                     }
                     for (; j + 4 <= cnt; j += 4) {
-                        u32 const s0 = codes[j], s1 = codes[j + 1], s2 = codes[j + 2], s3 = codes[j + 3];
-                        u32 const b0 = st.dnb[s0], b1 = st.dnb[s1], b2 = st.dnb[s2], b3 = st.dnb[s3];
-                        s32 const f0 = st.dfs[s0], f1 = st.dfs[s1], f2 = st.dfs[s2], f3 = st.dfs[s3];
+                        u32 const s0 = cCodes[j], s1 = cCodes[j + 1], s2 = cCodes[j + 2], s3 = cCodes[j + 3];
+                        u32 const b0 = cDnb[s0], b1 = cDnb[s1], b2 = cDnb[s2], b3 = cDnb[s3];
+                        s32 const f0 = cDfs[s0], f1 = cDfs[s1], f2 = cDfs[s2], f3 = cDfs[s3];
                         ZSA_CHAIN_STEP(b0, f0, j); ZSA_CHAIN_STEP(b1, f1, j + 1); ZSA_CHAIN_STEP(b2, f2, j + 2); ZSA_CHAIN_STEP(b3, f3, j + 3);
                     }
-                    for (; j < cnt; j++) { u32 const sy = codes[j]; u32 const bv = st.dnb[sy]; s32 const fv = st.dfs[sy]; ZSA_CHAIN_STEP(bv, fv, j); }
+                    for (; j < cnt; j++) { u32 const sy = cCodes[j]; u32 const bv = cDnb[sy]; s32 const fv = cDfs[sy]; ZSA_CHAIN_STEP(bv, fv, j); }
+                    st.value = value;
 #undef ZSA_CHAIN_STEP
                 }
                 wv_lds_fence();
@@ -1222,7 +1245,7 @@ ZSA_DEV u32 zsa_entropyCompress(ZsaEncShared* S, const u64* seq, u32 nbSeq, cons
                 if ((u32)(op - dst) + ((totalBits + 7) >> 3) > srcSize) return 0;
                 {   // flush whole words, carry the partial one
                     u32 const done = (totalBits >> 5) - flushedWords;
-                    for (u32 i = (u32)lane; i < done; i += ZSA_WAVE) { u32 const wv_ = E->bitbuf[i]; __builtin_memcpy(op + 4 * (flushedWords + i), &wv_, 4); }
+                    for (u32 i = (u32)lane; i < done; i += ZSA_WAVE) wv_stg32(op + 4 * (flushedWords + i), E->bitbuf[i]);
                     u32 const carry = E->bitbuf[done];
                     wv_lds_fence();
                     for (u32 i = (u32)lane; i <= done + 4 && i < 256; i += ZSA_WAVE) E->bitbuf[i] = 0;
@@ -1250,7 +1273,7 @@ ZSA_DEV u32 zsa_entropyCompress(ZsaEncShared* S, const u64* seq, u32 nbSeq, cons
 #undef ZSA_BLOB_ADD
             wv_lds_fence();
             u32 const totalBytes = (totalBits + 7) >> 3;
-            for (u32 i = flushedWords * 4 + (u32)lane; i < totalBytes; i += ZSA_WAVE) op[i] = ((const u8*)E->bitbuf)[i - flushedWords * 4];
+            for (u32 i = flushedWords * 4 + (u32)lane; i < totalBytes; i += ZSA_WAVE) wv_stg8(op + i, ((const u8*)E->bitbuf)[i - flushedWords * 4]);
             if (lane == 0) S->u[EU_tmp] = totalBytes;
         }
         wv_sync();

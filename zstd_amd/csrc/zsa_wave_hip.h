@@ -10,6 +10,9 @@
 #define ZSA_HD     __host__ __device__ inline
 #define ZSA_SHARED __shared__
 #define ZSA_WAVE   64
+// Qualifier of a pointer that is known to point into LDS: 32 bits wide, used by ds_* instructions as it is.  A generic pointer
+// that differs from lane to lane (one table per lane, say) costs a 64-bit addition and a null check per access -- or a flat load.
+#define ZSA_LDS    __attribute__((address_space(3)))
 
 ZSA_DEV int wv_lane() { return (int)(threadIdx.x & 63u); }
 ZSA_DEV unsigned long long wv_ballot(bool p) { return __ballot(p); }
@@ -93,23 +96,16 @@ ZSA_DEV void wv_atomic_max_global(unsigned* p, unsigned v) { (void)atomicMax(p, 
 // device-scope fence: afterwards plain loads of this wave observe earlier device-scope atomics (they bypass the L1)
 ZSA_DEV void wv_device_fence() { __threadfence(); }
 
-// inclusive prefix sum over the 64 lanes
-ZSA_DEV unsigned wv_scan_incl(unsigned v)
-{
-    const int lane = wv_lane();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { unsigned t = wv_shfl_up(v, d); if (lane >= d) v += t; }
-    return v;
-}
-ZSA_DEV unsigned wv_reduce_add(unsigned v)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += wv_shfl_xor(v, d);
-    return v;
-}
-ZSA_DEV unsigned wv_reduce_max(unsigned v)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { unsigned t = wv_shfl_xor(v, d); v = t > v ? t : v; }
-    return v;
-}
+// Inclusive prefix sum / sum / maximum over the 64 lanes on the data-parallel-primitive path of the vector unit: four row
+// shifts inside each row of 16 lanes, then the last lane of row 0 (2) broadcast into row 1 (3) and the last lane of row 1 into
+// rows 2 and 3 (GFX9's row_bcast:15 / row_bcast:31) -- six VALU operations without a trip through the LDS crossbar (the
+// shuffle-based forms they replace were six ds_bpermute round trips each).  Lanes without a source keep the identity (0).
+// All 64 lanes must be active.
+#define ZSA_DPP_STEP(op, v, ctrl, rowMask) v = op(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rowMask, 0xf, false))
+#define ZSA_DPP_SCAN(op, v) do { ZSA_DPP_STEP(op, v, 0x111, 0xf); ZSA_DPP_STEP(op, v, 0x112, 0xf); ZSA_DPP_STEP(op, v, 0x114, 0xf); \
+                                 ZSA_DPP_STEP(op, v, 0x118, 0xf); ZSA_DPP_STEP(op, v, 0x142, 0xa); ZSA_DPP_STEP(op, v, 0x143, 0xc); } while (0)
+ZSA_DEV unsigned wv_op_add(unsigned a, unsigned b) { return a + b; }
+ZSA_DEV unsigned wv_op_max(unsigned a, unsigned b) { return a > b ? a : b; }
+ZSA_DEV unsigned wv_scan_incl(unsigned v) { ZSA_DPP_SCAN(wv_op_add, v); return v; }
+ZSA_DEV unsigned wv_reduce_add(unsigned v) { ZSA_DPP_SCAN(wv_op_add, v); return wv_readlane(v, 63); }
+ZSA_DEV unsigned wv_reduce_max(unsigned v) { ZSA_DPP_SCAN(wv_op_max, v); return wv_readlane(v, 63); }
