@@ -425,6 +425,21 @@ ZSA_DEV u32 zsa_huf_buildTable(ZsaDecShared* S, const u8* src, u32 srcSize, int 
     return iSize + 1;
 }
 
+// up to 8 bytes of a match: dst[o .. o + len) = history[p .. p + len), where history is the frame's output so far (p >= 0) with the
+// dictionary's content in front of it (p < 0).  A full unit that does not straddle the seam is one 8-byte move.
+ZSA_DEV void zsa_copy_unit(u8* dst, const u8* dictContent, u32 dictSize, u32 o, s64 p, u32 len)
+{
+    if (len == 8 && (p >= 0 || p + 8 <= 0)) {
+        const u8* const from = p >= 0 ? dst + p : dictContent + ((s64)dictSize + p);
+        wv_stg64u(dst + o, wv_ldg64(from));
+    } else {
+        for (u32 j = 0; j < len; j++) {
+            s64 const q = p + j;
+            wv_stg8(dst + o + j, q < 0 ? wv_ldg8(dictContent + ((s64)dictSize + q)) : wv_ldg8(dst + q));
+        }
+    }
+}
+
 // huf_decompress.c:514-564: one stream, run by one lane.  Returns 0 ok / 1 corrupted.
 ZSA_DEV u32 zsa_huf_decodeStream(const ZsaDecShared* S, u8* p, u8* const pEnd, const u8* cSrc, u32 cSrcSize)
 {
@@ -1033,7 +1048,7 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
             for (u32 t = (u32)lane; t < totalLit; t += ZSA_WAVE) {
                 u32 lo = 0, hi = n - 1;
                 while (lo < hi) { u32 const mid = (lo + hi + 1) >> 1; if (S->litStart[mid] <= t) lo = mid; else hi = mid - 1; }
-                dst[outPos + S->outStart[lo] + (t - S->litStart[lo])] = litPtr[litPos + t];
+                wv_stg8(dst + outPos + S->outStart[lo] + (t - S->litStart[lo]), wv_ldg8(litPtr + litPos + t));
             }
             wv_lds_fence();
             ZSA_PROF(S, lane, 5);
@@ -1046,22 +1061,31 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
             // by the lane that owns the sequence, 8 bytes per instruction
             bool const owned = indep && myML <= 32 && myOF >= myML && myO >= myOF;
             if (owned) zsa_copy_run32(dst + myO, dst + myO - myOF, myML);
+            // The others are flattened over the lanes in UNITS: 8 bytes of a match that does not overlap its own output (all of
+            // its source is history), one byte of a match that does (offset < length: every byte is read from the first period).
             bool const flat = indep && !owned;
-            u32 const mIncl = wv_ballot(flat) ? wv_scan_incl(flat ? myML : 0) : 0;
-            S->mStart[lane] = mIncl - (flat ? myML : 0);
+            bool const wide = flat && myOF >= myML;
+            u32 const units = flat ? (wide ? (myML + 7) >> 3 : myML) : 0;
+            u32 const mIncl = wv_ballot(flat) ? wv_scan_incl(units) : 0;
+            S->mStart[lane] = mIncl - units;
+            S->litStart[lane] = wide ? 1u : 0u;     // (the literal stage is done with this array)
             u64 const depMask = wv_ballot((u32)lane < n && !indep && myML > 0);
             u32 const totalInd = wv_shfl(mIncl, 63);
             wv_lds_fence();
             for (u32 t = (u32)lane; t < totalInd; t += ZSA_WAVE) {
                 u32 lo = 0, hi = n - 1;
                 while (lo < hi) { u32 const mid = (lo + hi + 1) >> 1; if (S->mStart[mid] <= t) lo = mid; else hi = mid - 1; }
-                // lo = last sequence whose independent bytes start at or before t (sequences that contribute none share a start
+                // lo = last sequence whose units start at or before t (sequences that contribute none share a start
                 // with their successor and are skipped by taking the last)
                 u32 const k = t - S->mStart[lo];
                 u32 const off = S->seqOF[lo], ml = S->seqML[lo];
                 u32 const o = outPos + S->outStart[lo] + S->seqLL[lo];
-                s64 const p = (s64)o - (s64)off + (off >= ml ? k : k % off);
-                dst[o + k] = p < 0 ? C.dictContent[(s64)C.dictSize + p] : dst[p];
+                if (S->litStart[lo]) {
+                    u32 const b = 8u * k, len = (ml - b) < 8u ? (ml - b) : 8u;
+                    zsa_copy_unit(dst, C.dictContent, C.dictSize, o + b, (s64)o - (s64)off + b, len);
+                } else {
+                    zsa_copy_unit(dst, C.dictContent, C.dictSize, o + k, (s64)o - (s64)off + (k % off), 1);
+                }
             }
             // Phase II: the others.  A match may run as soon as every dependent match that produces part of its source has run; the
             // sequences its in-batch source bytes come from are a range of lanes (two searches in the output prefix sums),
@@ -1096,16 +1120,12 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                         u32 const i = (u32)__builtin_ctzll(m);
                         u32 const ml = S->seqML[i], off = S->seqOF[i];
                         u32 const o = outPos + S->outStart[i] + S->seqLL[i];
-                        if (off >= ml) {
-                            for (u32 t = (u32)lane; t < ml; t += ZSA_WAVE) {
-                                s64 const p = (s64)o - (s64)off + t;
-                                dst[o + t] = p < 0 ? C.dictContent[(s64)C.dictSize + p] : dst[p];
-                            }
+                        if (off >= ml) {   // 8 bytes per lane and step
+                            for (u32 b = 8u * (u32)lane; b < ml; b += 8u * ZSA_WAVE)
+                                zsa_copy_unit(dst, C.dictContent, C.dictSize, o + b, (s64)o - (s64)off + b, (ml - b) < 8u ? (ml - b) : 8u);
                         } else {
-                            for (u32 t = (u32)lane; t < ml; t += ZSA_WAVE) {
-                                s64 const p = (s64)o - (s64)off + (t % off);
-                                dst[o + t] = p < 0 ? C.dictContent[(s64)C.dictSize + p] : dst[p];
-                            }
+                            for (u32 t = (u32)lane; t < ml; t += ZSA_WAVE)
+                                zsa_copy_unit(dst, C.dictContent, C.dictSize, o + t, (s64)o - (s64)off + (t % off), 1);
                         }
                     }
                     notDone &= ~R;
@@ -1128,7 +1148,7 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
     // last literals (zstd_decompress_block.c:1644-1651)
     {   u32 const lastLL = litSize - litPos;
         if ((u64)outPos + lastLL > oendRel) { if (lane == 0) zsa_raise(S, ZSA_dstSize_tooSmall); wv_sync(); return 0; }
-        for (u32 t = (u32)lane; t < lastLL; t += ZSA_WAVE) dst[outPos + t] = litPtr[litPos + t];
+        for (u32 t = (u32)lane; t < lastLL; t += ZSA_WAVE) wv_stg8(dst + outPos + t, wv_ldg8(litPtr + litPos + t));
         outPos += lastLL;
     }
     wv_sync();
