@@ -1041,14 +1041,24 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
             if (S->err) return 0;
             u32 const totalLit = wv_shfl(litIncl, 63), totalOut = wv_shfl(totIncl, 63);
             // literals of the batch.  Runs of up to 32 bytes (nearly all of them on text-like data) are moved by the lane that owns
-            // the sequence, 8 bytes per instruction; a batch with a longer run is flattened over the lanes byte by byte.
-            if (!wv_ballot((u32)lane < n && myLL > 32)) {
-                if ((u32)lane < n) zsa_copy_run32(dst + outPos + myOutStart, litPtr + litPos + myLitStart, myLL);
-            } else
-            for (u32 t = (u32)lane; t < totalLit; t += ZSA_WAVE) {
-                u32 lo = 0, hi = n - 1;
-                while (lo < hi) { u32 const mid = (lo + hi + 1) >> 1; if (S->litStart[mid] <= t) lo = mid; else hi = mid - 1; }
-                wv_stg8(dst + outPos + S->outStart[lo] + (t - S->litStart[lo]), wv_ldg8(litPtr + litPos + t));
+            // the sequence, 8 bytes per instruction; the longer ones are flattened over the lanes in units of 8 bytes (the last
+            // unit of a run is moved back to end with the run: one move as well).
+            if ((u32)lane < n && myLL <= 32) zsa_copy_run32(dst + outPos + myOutStart, litPtr + litPos + myLitStart, myLL);
+            if (wv_ballot((u32)lane < n && myLL > 32)) {
+                u32 const units = ((u32)lane < n && myLL > 32) ? (myLL + 7) >> 3 : 0;
+                u32 const uIncl = wv_scan_incl(units);
+                S->mStart[lane] = uIncl - units;
+                u32 const totalUnits = wv_shfl(uIncl, 63);
+                wv_lds_fence();
+                for (u32 t = (u32)lane; t < totalUnits; t += ZSA_WAVE) {
+                    u32 lo = 0, hi = n - 1;
+                    while (lo < hi) { u32 const mid = (lo + hi + 1) >> 1; if (S->mStart[mid] <= t) lo = mid; else hi = mid - 1; }
+                    u32 const ll = S->seqLL[lo];
+                    u32 b = 8u * (t - S->mStart[lo]);
+                    if (ll - b < 8u) b = ll - 8u;   // (ll > 32)
+                    wv_stg64u(dst + outPos + S->outStart[lo] + b, wv_ldg64(litPtr + litPos + S->litStart[lo] + b));
+                }
+                wv_lds_fence();   // (mStart is written again by the match stage)
             }
             wv_lds_fence();
             ZSA_PROF(S, lane, 5);
@@ -1081,7 +1091,10 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                 u32 const off = S->seqOF[lo], ml = S->seqML[lo];
                 u32 const o = outPos + S->outStart[lo] + S->seqLL[lo];
                 if (S->litStart[lo]) {
-                    u32 const b = 8u * k, len = (ml - b) < 8u ? (ml - b) : 8u;
+                    // (the last unit of a match of 8 bytes or more is moved back to end with the match: it then overlaps its
+                    // predecessor with the same bytes -- source and destination of such a match are disjoint -- and stays one move)
+                    u32 b = 8u * k, len = (ml - b) < 8u ? (ml - b) : 8u;
+                    if (len < 8u && ml >= 8u) { b = ml - 8u; len = 8u; }
                     zsa_copy_unit(dst, C.dictContent, C.dictSize, o + b, (s64)o - (s64)off + b, len);
                 } else {
                     zsa_copy_unit(dst, C.dictContent, C.dictSize, o + k, (s64)o - (s64)off + (k % off), 1);
@@ -1121,8 +1134,11 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                         u32 const ml = S->seqML[i], off = S->seqOF[i];
                         u32 const o = outPos + S->outStart[i] + S->seqLL[i];
                         if (off >= ml) {   // 8 bytes per lane and step
-                            for (u32 b = 8u * (u32)lane; b < ml; b += 8u * ZSA_WAVE)
-                                zsa_copy_unit(dst, C.dictContent, C.dictSize, o + b, (s64)o - (s64)off + b, (ml - b) < 8u ? (ml - b) : 8u);
+                            for (u32 b0 = 8u * (u32)lane; b0 < ml; b0 += 8u * ZSA_WAVE) {
+                                u32 b = b0, len = (ml - b) < 8u ? (ml - b) : 8u;
+                                if (len < 8u && ml >= 8u) { b = ml - 8u; len = 8u; }
+                                zsa_copy_unit(dst, C.dictContent, C.dictSize, o + b, (s64)o - (s64)off + b, len);
+                            }
                         } else {
                             for (u32 t = (u32)lane; t < ml; t += ZSA_WAVE)
                                 zsa_copy_unit(dst, C.dictContent, C.dictSize, o + t, (s64)o - (s64)off + (t % off), 1);

@@ -95,7 +95,7 @@ struct ZsaEncShared {
                     };
                     ZsaFseCT ll, of, ml;
                 };
-                struct { u32 bLit[64], bSrc[64]; };   // literal gather
+                struct { u32 bLit[64], bSrc[64], bLen[64], bDst[64]; };   // literal gather: unit start, source, length, destination of a run
             };
         };
         struct {   // parse stage (zsa_parse.h): source ring + filter + cell bitmap / shared-cell tags
@@ -1313,16 +1313,23 @@ ZSA_DEV void zsa_gatherLiterals(ZsaEncShared* S, const u64* seq, u32 nbSeq, cons
         u32 const litIncl = wv_scan_incl(ll), totIncl = wv_scan_incl(tot);
         u32 const totalLit = wv_shfl(litIncl, 63), totalSrc = wv_shfl(totIncl, 63);
         // Runs of up to 32 bytes (nearly all of them on text-like data) are moved by the lane that owns the sequence, 8 bytes
-        // per instruction; a batch with a longer run is flattened over the lanes byte by byte.
-        if (!wv_ballot(ll > 32)) {
-            if ((u32)lane < n) zsa_copy_run32(lit + litPos + (litIncl - ll), src + srcPos + (totIncl - tot), ll);
-        } else {
-            S->bLit[lane] = litIncl - ll; S->bSrc[lane] = totIncl - tot;
+        // per instruction; the longer ones are flattened over the lanes in units of 8 bytes (the last unit of a run is moved
+        // back to end with the run).
+        if ((u32)lane < n && ll <= 32) zsa_copy_run32(lit + litPos + (litIncl - ll), src + srcPos + (totIncl - tot), ll);
+        if (wv_ballot(ll > 32)) {
+            u32 const units = ll > 32 ? (ll + 7) >> 3 : 0;
+            u32 const uIncl = wv_scan_incl(units);
+            S->bLit[lane] = uIncl - units;
+            S->bSrc[lane] = totIncl - tot; S->bLen[lane] = ll; S->bDst[lane] = litIncl - ll;
+            u32 const totalUnits = wv_shfl(uIncl, 63);
             wv_lds_fence();
-            for (u32 t = (u32)lane; t < totalLit; t += ZSA_WAVE) {
+            for (u32 t = (u32)lane; t < totalUnits; t += ZSA_WAVE) {
                 u32 lo = 0, hi = n - 1;
                 while (lo < hi) { u32 const mid = (lo + hi + 1) >> 1; if (S->bLit[mid] <= t) lo = mid; else hi = mid - 1; }
-                lit[litPos + t] = src[srcPos + S->bSrc[lo] + (t - S->bLit[lo])];
+                u32 const runLL = S->bLen[lo], runLit = S->bDst[lo];
+                u32 b = 8u * (t - S->bLit[lo]);
+                if (runLL - b < 8u) b = runLL - 8u;   // (runLL > 32)
+                wv_stg64u(lit + litPos + runLit + b, wv_ldg64(src + srcPos + S->bSrc[lo] + b));
             }
             wv_lds_fence();
         }
