@@ -98,6 +98,7 @@ ZSA_DEV void wv_stg_cell(unsigned* p, unsigned v) { *p = v; }
 ZSA_DEV void wv_stg64(void* p, unsigned long long v) { *(unsigned long long*)p = v; }
 ZSA_DEV void wv_stg32(void* p, unsigned v) { memcpy(p, &v, 4); }
 ZSA_DEV void wv_stg64u(void* p, unsigned long long v) { memcpy(p, &v, 8); }
+ZSA_DEV void wv_stg16(void* p, unsigned v) { unsigned short w = (unsigned short)v; memcpy(p, &w, 2); }
 ZSA_DEV void wv_stg8(unsigned char* p, unsigned v) { *p = (unsigned char)v; }
 ZSA_DEV unsigned wv_ldg8_now(const unsigned char* p) { return wv_ldg8(p); }
 ZSA_DEV unsigned wv_ldg32_now(const unsigned char* p) { return wv_ldg32(p); }

@@ -45,7 +45,6 @@ struct __attribute__((aligned(16))) ZsaDecShared {
         u16 huf[1 << ZSA_HUF_TABLELOG_MAX];                     // literal phase
         struct { ZsaSeqCell ll[512], ml[512], of[256]; };        // sequence phase
     };
-    u32 hufLog, llLog, ofLog, mlLog;
     union {
         struct {   // table-building scratch
             u8  weights[256];
@@ -61,12 +60,20 @@ struct __attribute__((aligned(16))) ZsaDecShared {
             u8  bits[ZSA_BITSTAGE + 16];
         };
     };
+    u32 hufLog, llLog, ofLog, mlLog;
     // uniform state published by lane 0
     u64 result;                 // final return value of the frame walk
     u32 err;                    // first error raised inside the current block (0 = none)
     u32 u[16];
     u64 prof[ZSA_NPROF], profLast;
 };
+// While a block's Huffman streams are decoded nothing else of a block lives in LDS: the single-symbol table lies in the first
+// 4 KiB and a table of symbol PAIRS (zsa_huf_buildPairs), 4 bytes per cell, takes the 8 KiB behind it -- the rest of the first
+// union and the head of the second.
+// (tables of up to 2048 cells: what libzstd's encoder produces; a 4096-cell table, which the format allows, is decoded without pairs)
+static_assert(offsetof(ZsaDecShared, weights) == 10240 && offsetof(ZsaDecShared, hufLog) >= 4096 + 4 * 2048,
+              "the pair table overlays the sequence tables and the batch arrays");
+ZSA_DEV u32* zsa_huf_pairTable(ZsaDecShared* S) { return (u32*)((u8*)S + 4096); }
 // per-workgroup global workspace: regenerated literals of the block at hand, then the parked tables
 struct __attribute__((aligned(16))) ZsaDecBackup { u16 huf[1 << ZSA_HUF_TABLELOG_MAX]; ZsaSeqCell ll[512], ml[512], of[256]; };
 #define ZSA_DEC_LITBUF_BYTES (ZSA_BLOCKSIZE_MAX + 128u)
@@ -440,8 +447,25 @@ ZSA_DEV void zsa_copy_unit(u8* dst, const u8* dictContent, u32 dictSize, u32 o, 
     }
 }
 
-// huf_decompress.c:514-564: one stream, run by one lane.  Returns 0 ok / 1 corrupted.
-ZSA_DEV u32 zsa_huf_decodeStream(const ZsaDecShared* S, u8* p, u8* const pEnd, const u8* cSrc, u32 cSrcSize)
+// Symbol pairs: cell i of the pair table holds the symbol the single table has there and, where the bits that are left of the
+// index behind that symbol's code determine a second code completely, that second symbol too (what libzstd's X2 tables do
+// for the decoder that uses them; the symbols that come out are the same whichever table decodes them).
+// Cell: symbol 1 | symbol 2 << 8 | bits of both << 16 | (second symbol present) << 24.
+ZSA_DEV void zsa_huf_buildPairs(ZsaDecShared* S, int lane)
+{
+    u32 const log = S->hufLog, size = 1u << log;
+    u32* const pair = zsa_huf_pairTable(S);
+    for (u32 i = (u32)lane; i < size; i += ZSA_WAVE) {
+        u32 const c1 = S->huf[i], l1 = c1 >> 8;
+        u32 const c2 = S->huf[(i << l1) & (size - 1u)], l2 = c2 >> 8;
+        bool const two = l1 + l2 <= log;
+        pair[i] = (c1 & 0xFFu) | (two ? (c2 & 0xFFu) << 8 : 0u) | ((two ? l1 + l2 : l1) << 16) | ((two ? 1u : 0u) << 24);
+    }
+    wv_sync();
+}
+
+// huf_decompress.c:514-564: one stream, run by one lane.  Returns 0 ok / 1 corrupted.  `pair`: the pair table, or null.
+ZSA_DEV u32 zsa_huf_decodeStream(const ZsaDecShared* S, u8* p, u8* const pEnd, const u8* cSrc, u32 cSrcSize, const u32* pair)
 {
     ZsaBitR b;
     if (zsa_br_init(b, cSrc, cSrcSize)) return 1;
@@ -454,6 +478,27 @@ ZSA_DEV u32 zsa_huf_decodeStream(const ZsaDecShared* S, u8* p, u8* const pEnd, c
         if (zsa_br_reload(b) == ZB_unfinished && b.ptr >= b.start + 16) {
             const u8* ptr = b.ptr; u32 bc = b.bitsConsumed; u64 W = b.container;
             u64 below = wv_ldg64(ptr - 8);
+            if (pair) {
+                // four cells, then a refill, as below -- but a cell yields one or two symbols: both bytes are stored and the
+                // output moves on by as many as count (a byte stored in excess is overwritten by the next store; eight bytes
+                // of room keep the last one inside this stream's part of the output)
+                while (ptr >= b.start + 16 && (size_t)(pEnd - p) >= 8) {
+                    u64 X = W << bc;
+#pragma unroll
+                    for (u32 k = 0; k < 4; k++) {
+                        u32 const c = pair[(u32)(X >> (64u - dtLog))];
+                        u32 const nbits = (c >> 16) & 0xFu;
+                        X <<= nbits; bc += nbits;
+                        wv_stg16(p, c & 0xFFFFu);
+                        p += 1u + (c >> 24);
+                    }
+                    u32 const nb = bc >> 3;
+                    bc &= 7;
+                    if (nb) W = (W << (8u * nb)) | (below >> (64u - 8u * nb));
+                    ptr -= nb;
+                    below = wv_ldg64(ptr - 8);
+                }
+            }
             while (ptr >= b.start + 16 && p < pEnd - 3) {
                 u64 X = W << bc;
                 u32 out = 0;
@@ -646,8 +691,10 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
         }
         // streams: huf_decompress.c:543-666
         u32 bad = 0;
+        const u32* pairs = nullptr;
+        if (litSize >= 2048 && S->hufLog <= 11) { zsa_huf_buildPairs(S, lane); pairs = zsa_huf_pairTable(S); }   // (pays from a few hundred symbols per stream on)
         if (streams == 1) {
-            if (lane == 0) bad = zsa_huf_decodeStream(S, litBuf, litBuf + litSize, cSrc, cSrcSize);
+            if (lane == 0) bad = zsa_huf_decodeStream(S, litBuf, litBuf + litSize, cSrc, cSrcSize, pairs);
         } else {
             if (cSrcSize < 10) bad = 1;
             else {
@@ -662,7 +709,7 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                     u32 const len = lane == 0 ? l1 : (lane == 1 ? l2 : (lane == 2 ? l3 : l4));
                     u8* const o0 = litBuf + (u32)lane * segmentSize;
                     u8* const o1 = lane == 3 ? litBuf + litSize : o0 + segmentSize;
-                    bad = zsa_huf_decodeStream(S, o0, o1, cSrc + off, len);
+                    bad = zsa_huf_decodeStream(S, o0, o1, cSrc + off, len, pairs);
                 }
             }
         }

@@ -73,6 +73,8 @@ ZSA_DEV void wv_stg_cell(unsigned* p, unsigned v) { *(__attribute__((address_spa
 ZSA_DEV void wv_stg64(void* p, unsigned long long v) { *(__attribute__((address_space(1))) unsigned long long*)p = v; }
 ZSA_DEV void wv_stg32(void* p, unsigned v) { ((__attribute__((address_space(1))) WvPk32*)p)->v = v; }
 ZSA_DEV void wv_stg64u(void* p, unsigned long long v) { ((__attribute__((address_space(1))) WvPk64*)p)->v = v; }   // unaligned
+struct __attribute__((packed)) WvPk16 { unsigned short v; };
+ZSA_DEV void wv_stg16(void* p, unsigned v) { ((__attribute__((address_space(1))) WvPk16*)p)->v = (unsigned short)v; }   // unaligned
 ZSA_DEV void wv_stg8(unsigned char* p, unsigned v) { *(__attribute__((address_space(1))) unsigned char*)p = (unsigned char)v; }
 // The same loads, completed before control leaves the call.  For the rarely-taken global side of an "LDS or global"
 // read: gfx950 counts loads and stores in one counter (vmcnt), so if a pending load could reach the join of the two
