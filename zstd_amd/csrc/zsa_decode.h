@@ -479,13 +479,13 @@ ZSA_DEV u32 zsa_huf_decodeStream(const ZsaDecShared* S, u8* p, u8* const pEnd, c
             const u8* ptr = b.ptr; u32 bc = b.bitsConsumed; u64 W = b.container;
             u64 below = wv_ldg64(ptr - 8);
             if (pair) {
-                // four cells, then a refill, as below -- but a cell yields one or two symbols: both bytes are stored and the
-                // output moves on by as many as count (a byte stored in excess is overwritten by the next store; eight bytes
+                // five cells, then a refill -- a cell yields one or two symbols: both bytes are stored and the
+                // output moves on by as many as count (a byte stored in excess is overwritten by the next store; ten bytes
                 // of room keep the last one inside this stream's part of the output)
-                while (ptr >= b.start + 16 && (size_t)(pEnd - p) >= 8) {
-                    u64 X = W << bc;
+                while (ptr >= b.start + 16 && (size_t)(pEnd - p) >= 10) {
+                    u64 X = W << bc;   // (57 bits at least: five cells of up to 11)
 #pragma unroll
-                    for (u32 k = 0; k < 4; k++) {
+                    for (u32 k = 0; k < 5; k++) {
                         u32 const c = pair[(u32)(X >> (64u - dtLog))];
                         u32 const nbits = (c >> 16) & 0xFu;
                         X <<= nbits; bc += nbits;
