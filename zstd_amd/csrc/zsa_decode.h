@@ -74,6 +74,27 @@ struct __attribute__((aligned(16))) ZsaDecShared {
 static_assert(offsetof(ZsaDecShared, weights) == 10240 && offsetof(ZsaDecShared, hufLog) >= 4096 + 4 * 2048,
               "the pair table overlays the sequence tables and the batch arrays");
 ZSA_DEV u32* zsa_huf_pairTable(ZsaDecShared* S) { return (u32*)((u8*)S + 4096); }
+// The table descriptions of a block (Huffman weights, the three FSE distributions) are read by one lane, a few bits per symbol,
+// every step waiting for the bytes of the step before: read from the frame in global memory that is one memory round trip per
+// symbol or two.  So all lanes first copy the description's bytes into LDS that no stage of table construction uses -- the
+// tail of the batch bit stage, behind the table-building scratch -- and the reader runs there.  A valid description is at
+// most 128 bytes (Huffman weights: the size byte says so) or 85 (53 symbols of at most 10 + 2 bits); a reader that leaves the
+// staged bytes fails on them exactly as it would fail on the frame's (zsa_readNCount pads with zeros and reports the overrun).
+#define ZSA_HDRSTAGE 192u
+#define ZSA_HDRSTAGE_AT 576u
+static_assert(offsetof(ZsaDecShared, bits) + ZSA_HDRSTAGE_AT >= offsetof(ZsaDecShared, rankVal) + sizeof(((ZsaDecShared*)0)->rankVal)
+              && ZSA_HDRSTAGE_AT + ZSA_HDRSTAGE <= sizeof(((ZsaDecShared*)0)->bits), "the header stage lies behind the table-building scratch");
+ZSA_DEV u8* zsa_hdr_stage(ZsaDecShared* S) { return S->bits + ZSA_HDRSTAGE_AT; }
+ZSA_DEV u32 zsa_stage_header(ZsaDecShared* S, const u8* p, u32 n, int lane)
+{   // returns the number of bytes staged (uniform)
+    u32 const m = n < ZSA_HDRSTAGE ? n : ZSA_HDRSTAGE;
+    u8* const st = zsa_hdr_stage(S);
+    u32 const i0 = (u32)lane, i1 = i0 + ZSA_WAVE, i2 = i1 + ZSA_WAVE;
+    u32 const b0 = i0 < m ? wv_ldg8(p + i0) : 0u, b1 = i1 < m ? wv_ldg8(p + i1) : 0u, b2 = i2 < m ? wv_ldg8(p + i2) : 0u;
+    st[i0] = (u8)b0; st[i1] = (u8)b1; st[i2] = (u8)b2;
+    wv_lds_fence();
+    return m;
+}
 // per-workgroup global workspace: regenerated literals of the block at hand, then the parked tables
 struct __attribute__((aligned(16))) ZsaDecBackup { u16 huf[1 << ZSA_HUF_TABLELOG_MAX]; ZsaSeqCell ll[512], ml[512], of[256]; };
 #define ZSA_DEC_LITBUF_BYTES (ZSA_BLOCKSIZE_MAX + 128u)
@@ -168,7 +189,8 @@ ZSA_DEV u32 zsa_peekbits(const u8* src, u32 n, u32 bitPos)
 {   // 25+ bits starting at bitPos
     u32 const by = bitPos >> 3, sh = bitPos & 7;
     u64 v = 0;
-    for (u32 i = 0; i < 5; i++) if (by + i < n) v |= (u64)src[by + i] << (8 * i);
+    if (by + 8 <= n) v = zsa_ld64(src + by);
+    else for (u32 i = 0; i < 5; i++) if (by + i < n) v |= (u64)src[by + i] << (8 * i);
     return (u32)(v >> sh);
 }
 ZSA_DEV u32 zsa_readNCount(s16* norm, u32* maxSVPtr, u32* tableLogPtr, const u8* src, u32 hbSize, u32* err)
@@ -336,14 +358,16 @@ ZSA_DEV u32 zsa_huf_buildTable(ZsaDecShared* S, const u8* src, u32 srcSize, int 
 {
     u8* const huffWeight = S->weights;
     u32 mode = 0, iSize = 0, oSize = 0, wLog = 0, wMax = 0, nc = 0;   // mode 0: error, 1: 4-bit weights, 2: FSE, 3: done by lane 0 alone
+    const u8* const hdr = zsa_hdr_stage(S);                              // the description (at most 1 + 127 bytes) in LDS
+    zsa_stage_header(S, src, srcSize, lane);
     if (lane == 0 && srcSize) {
-        iSize = src[0];
+        iSize = hdr[0];
         if (iSize >= 128) {
             oSize = iSize - 127; iSize = (oSize + 1) / 2;
             if (iSize + 1 <= srcSize) mode = 1;                  // (oSize <= 128)
         } else if (iSize + 1 <= srcSize) {
             u32 e = 0; wMax = 255;
-            nc = zsa_readNCount(S->norm, &wMax, &wLog, src + 1, iSize, &e);
+            nc = zsa_readNCount(S->norm, &wMax, &wLog, hdr + 1, iSize, &e);
             if (!e && wLog <= 6) mode = 2;
         }
     }
@@ -351,7 +375,7 @@ ZSA_DEV u32 zsa_huf_buildTable(ZsaDecShared* S, const u8* src, u32 srcSize, int 
     wLog = wv_readlane(wLog, 0); wMax = wv_readlane(wMax, 0); nc = wv_readlane(nc, 0);
     wv_sync();
     if (mode == 1) {
-        if (2u * (u32)lane < oSize) { u32 const b = src[1 + lane]; huffWeight[2 * lane] = (u8)(b >> 4); huffWeight[2 * lane + 1] = (u8)(b & 15); }
+        if (2u * (u32)lane < oSize) { u32 const b = hdr[1 + lane]; huffWeight[2 * lane] = (u8)(b >> 4); huffWeight[2 * lane + 1] = (u8)(b & 15); }
     } else if (mode == 2) {
         if (wMax > 63) {   // more weight values than a valid description can hold: the serial routine decides (and fails later)
             u32 n = 0, tl = 0, h = 0;
@@ -370,7 +394,7 @@ ZSA_DEV u32 zsa_huf_buildTable(ZsaDecShared* S, const u8* src, u32 srcSize, int 
             });
             wv_sync();
             u32 n = 0;
-            if (lane == 0) n = zsa_huf_decodeWeights(S, src + 1 + nc, iSize - nc, wLog);
+            if (lane == 0) n = zsa_huf_decodeWeights(S, hdr + 1 + nc, iSize - nc, wLog);
             oSize = wv_readlane(n, 0);
             if (!oSize) mode = 0;
         }
@@ -573,9 +597,10 @@ ZSA_DEV u32 zsa_buildSeqTableFromHeader(ZsaDecShared* S, ZsaSeqCell* cell, u32* 
         return 0;
     default: {
         u32 tableLog = 0, maxSV = max, h = 0;
+        u32 const staged = zsa_stage_header(S, src, srcSize, lane);
         if (lane == 0) {
             u32 err = 0;
-            h = zsa_readNCount(S->norm, &maxSV, &tableLog, src, srcSize, &err);
+            h = zsa_readNCount(S->norm, &maxSV, &tableLog, zsa_hdr_stage(S), staged, &err);
             if (err || tableLog > maxLog) { S->err = ZSA_corruption_detected; tableLog = 0; }
             else *logPtr = tableLog;
         }
