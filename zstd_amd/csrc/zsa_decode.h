@@ -847,84 +847,13 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
             // -- zstd_decompress_block.c:1185-1299 ZSTD_decodeSequence, n times on lane 0.  (Measured, round 2: the same loop run by
             // the whole wave on scalar registers -- one LDS round trip and ~70 scalar instructions per sequence -- is no faster:
             // 12 resident waves share the CU's one scalar unit, whereas lane-0 vector code spreads over four SIMDs.)
-            // Interior batches -- the 64 x 89 bits a batch can consume at most all lie above the first 8 bytes of the section,
-            // so none of the reader's end-of-buffer cases can arise -- take a reader of their own: one bit cursor into the
-            // staged bytes, the six fields of a sequence cut from one 64-bit window, and the next sequence's window requested
-            // as soon as the three cells tell how many bits this one consumes (the refill then rides on the same LDS round
-            // trip as the next cells).  The state it leaves is the one BIT_reloadDStream leaves after every sequence.
-            // (b lives in lane 0: the flag is taken from there)
-            bool const interior = wv_readlane((b.bitsConsumed < 8 && (size_t)(b.ptr - b.start) >= 8u + (64u * 89u + 7u) / 8u + 8u) ? 1u : 0u, 0) != 0;
-#ifdef ZSA_DEC_SERIAL_FIELDS
-            if (lane == 0 && interior) {
-                struct __attribute__((packed)) Pk { u64 v; };
-                u32 pOff = (u32)(b.ptr - stageLo), bc = b.bitsConsumed;
-                u64 W = ((const Pk*)(S->bits + pOff))->v;
-#define ZSA_TAKE(v, nb) do { v = (u32)((X >> 1) >> (63u - (nb))); X <<= (nb); } while (0)
-                for (u32 i = 0; i < n; i++) {
-                    ZsaSeqCell const ll = S->ll[stLL], ml = S->ml[stML], of = S->of[stOF];
-                    u32 const llH = (u32)(ll >> 32), mlH = (u32)(ml >> 32), ofH = (u32)(of >> 32);
-                    u32 const ofBits = (ofH >> 16) & 0xFF, mlBits = (mlH >> 16) & 0xFF, llBits = (llH >> 16) & 0xFF;
-                    u32 const llS = llH >> 24, mlS = mlH >> 24, ofS = ofH >> 24;
-                    // (the fields are cut from the top down: `at` = lowest bit of the field at hand, counted in the top 32 bits of the
-                    // window -- one subtraction and one bit-field extract per field, and 32 - at is the number of bits taken)
-                    u32 const at1 = 32u - ofBits, at2 = at1 - mlBits, at3 = at2 - llBits, at4 = at3 - llS, at5 = at4 - mlS, at6 = at5 - ofS;
-                    u32 ofx, mlx, llx, sl, sm, so;
-                    u32 const used = bc + 32u - at6;
-                    if ((s32)(at6 - bc) >= 0) {   // the usual case: all six fields lie in the top 32 bits of the window
-                        u32 const top = (u32)((W << bc) >> 32);
-                        pOff -= used >> 3; bc = used & 7;
-                        W = ((const Pk*)(S->bits + pOff))->v;
-                        ofx = wv_bfe(top, at1, ofBits); mlx = wv_bfe(top, at2, mlBits); llx = wv_bfe(top, at3, llBits);
-                        sl = wv_bfe(top, at4, llS); sm = wv_bfe(top, at5, mlS); so = wv_bfe(top, at6, ofS);
-                    } else
-                    if (used <= 64) {
-                        u64 X = W << bc;
-                        pOff -= used >> 3; bc = used & 7;
-                        W = ((const Pk*)(S->bits + pOff))->v;
-                        ZSA_TAKE(ofx, ofBits); ZSA_TAKE(mlx, mlBits); ZSA_TAKE(llx, llBits);
-                        ZSA_TAKE(sl, llS); ZSA_TAKE(sm, mlS); ZSA_TAKE(so, ofS);
-                    } else {   // more than a window holds: refill after the offset and match-length bits (<= 7 + 31 + 16)
-                        u64 X = W << bc;
-                        ZSA_TAKE(ofx, ofBits); ZSA_TAKE(mlx, mlBits);
-                        {   u32 const u1 = bc + ofBits + mlBits;
-                            pOff -= u1 >> 3; bc = u1 & 7;
-                            W = ((const Pk*)(S->bits + pOff))->v; X = W << bc;
-                        }
-                        ZSA_TAKE(llx, llBits); ZSA_TAKE(sl, llS); ZSA_TAKE(sm, mlS); ZSA_TAKE(so, ofS);
-                        {   u32 const u2 = bc + llBits + llS + mlS + ofS;
-                            pOff -= u2 >> 3; bc = u2 & 7;
-                            W = ((const Pk*)(S->bits + pOff))->v;
-                        }
-                    }
-                    // offset and repeat-offset history (zstd_decompress_block.c:1236-1269).  (Branches on purpose: the common
-                    // case, a new offset, is three moves; the same logic written with selects measured 25 % slower.)
-                    u32 offset;
-                    if (ofBits > 1) {
-                        offset = (u32)of + ofx;
-                        r2 = r1; r1 = r0; r0 = offset;
-                    } else {
-                        u32 const ll0 = ((u32)ll == 0);
-                        if (ofBits == 0) {
-                            offset = ll0 ? r1 : r0;
-                            r1 = ll0 ? r0 : r1;
-                            r0 = offset;
-                        } else {
-                            u32 const code = (u32)of + ll0 + ofx;
-                            u32 temp = (code == 3) ? r0 - 1 : (code == 1 ? r1 : (code == 2 ? r2 : r0));
-                            temp += !temp;
-                            if (code != 1) r2 = r1;
-                            r1 = r0;
-                            r0 = offset = temp;
-                        }
-                    }
-                    S->seqLL[i] = (u32)ll + llx; S->seqML[i] = (u32)ml + mlx; S->seqOF[i] = offset;
-                    stLL = (llH & 0xFFFF) + sl; stML = (mlH & 0xFFFF) + sm; stOF = (ofH & 0xFFFF) + so;
-                }
-#undef ZSA_TAKE
-                b.ptr = stageLo + pOff; b.bitsConsumed = bc; b.container = W;
-                S->u[ZU_batchN] = (nbSeq == n) && (ZSA_RELOAD(b) < ZB_completed);
-            }
-#else
+            // A sequence that starts 16 bytes or more above the staged slice's first byte -- it consumes at most 89 bits, in at most
+            // two refills of less than 8 bytes each -- meets none of the reader's end-of-buffer cases, and takes a reader of its own:
+            // one bit cursor into the staged bytes, the six fields of a sequence cut from one 64-bit window, and the next
+            // sequence's window requested as soon as the three cells tell how many bits this one consumes (the refill then rides
+            // on the same LDS round trip as the next cells).  The state it leaves is the one BIT_reloadDStream leaves after every
+            // sequence.  The first k sequences of the batch go this way -- all 64 of an interior batch, all but the last few of a
+            // section's last batch (which is the only batch of a small frame) -- and the reference's reader below takes the rest.
             // What is serial in a sequence is the walk from one triple of FSE states to the next: three cells, the number of bits
             // they consume, the three state fields.  So lane 0 does just that per sequence and leaves a RECORD -- the 64-bit window
             // at the sequence's first bit and the three states it was decoded in (four words, in the batch arrays the execution
@@ -932,12 +861,17 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
             // lanes afterwards, one sequence per lane: extra bits, lengths, the offset or the repeat-offset code.  The repeat-offset
             // history is the other chain; it is replayed over the repeat codes only (new offsets between two of them are applied in
             // one step), in uniform control flow.
-            if (lane == 0 && interior) {
+            u32 k = 0;
+#define ZSA_TAKE(v, nb) do { v = (u32)((X >> 1) >> (63u - (nb))); X <<= (nb); } while (0)
+            if (lane == 0 && b.bitsConsumed < 8 && b.ptr + 8 <= stageHi && (size_t)(b.ptr - stageLo) >= 16) {
                 struct __attribute__((packed)) Pk { u64 v; };
                 u32 pOff = (u32)(b.ptr - stageLo), bc = b.bitsConsumed;
                 u64 W = ((const Pk*)(S->bits + pOff))->v;
-#define ZSA_TAKE(v, nb) do { v = (u32)((X >> 1) >> (63u - (nb))); X <<= (nb); } while (0)
-                for (u32 i = 0; i < n; i++) {
+                u32 i = 0;
+                // (a sequence moves the cursor down by 12 bytes at most: `safe` sequences need no look at it)
+                while (wv_single_lane_b(i < n && pOff >= 16u)) {
+                u32 const safe = (pOff - 16u) / 12u + 1u, iEnd = (n - i) < safe ? n : i + safe;
+                for (; i < iEnd; i++) {
                     ZsaSeqCell const ll = S->ll[stLL], ml = S->ml[stML], of = S->of[stOF];
                     u32 const llH = (u32)(ll >> 32), mlH = (u32)(ml >> 32), ofH = (u32)(of >> 32);
                     // the three high words added as they are: byte 2 = extra bits of the sequence, byte 3 = state bits (the low
@@ -980,12 +914,15 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                     S->seqLL[i] = (u32)X0; S->seqML[i] = (u32)(X0 >> 32); S->seqOF[i] = pk; S->outStart[i] = pk2;
                     stLL = (llH & 0xFFFF) + sl; stML = (mlH & 0xFFFF) + sm; stOF = (ofH & 0xFFFF) + so;
                 }
+                }
+                k = i;
                 b.ptr = stageLo + pOff; b.bitsConsumed = bc; b.container = W;
-                S->u[ZU_batchN] = (nbSeq == n) && (ZSA_RELOAD(b) < ZB_completed);
+                if (k == n) S->u[ZU_batchN] = (nbSeq == n) && (ZSA_RELOAD(b) < ZB_completed);
             }
-            if (interior) {
+            k = wv_readlane(k, 0);
+            if (k) {
                 wv_lds_fence();
-                bool const act = (u32)lane < n;
+                bool const act = (u32)lane < k;
                 u32 vLL = 0, vML = 0, vOF = 1, rc = 0;
                 bool isN = false;
                 if (act) {
@@ -1010,7 +947,7 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                 u64 rm = repMask;
                 u32 pos = 0;
                 for (;;) {
-                    u32 const j = rm ? (u32)__builtin_ctzll(rm) : n;
+                    u32 const j = rm ? (u32)__builtin_ctzll(rm) : k;
                     // the new offsets of [pos, j): the last three of them are what is left in the history
                     u64 ns = pos < 64 ? (newMask >> pos) << pos : 0;
                     if (j < 64) ns &= ((u64)1 << j) - 1u;
@@ -1046,9 +983,8 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                 r0 = q0; r1 = q1; r2 = q2;   // (every lane's copy: lane 0's is the one the serial reader below carries on with)
                 wv_lds_fence();
             }
-#endif
-            if (lane == 0 && !interior) {
-                for (u32 i = 0; i < n; i++) {
+            if (lane == 0 && k < n) {   // the reference's reader, end-of-buffer cases and all, for what the walk above left
+                for (u32 i = k; i < n; i++) {
                     ZsaSeqCell const ll = S->ll[stLL], ml = S->ml[stML], of = S->of[stOF];
                     u32 matchLength = (u32)ml, litLength = (u32)ll, offset;
                     u32 const llBits = (u32)(ll >> 48) & 0xFF, mlBits = (u32)(ml >> 48) & 0xFF, ofBits = (u32)(of >> 48) & 0xFF;
