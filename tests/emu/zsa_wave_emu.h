@@ -84,6 +84,7 @@ ZSA_DEV unsigned wv_uniform(unsigned v, int line = __builtin_LINE()) { return (u
 ZSA_DEV bool wv_uniform_b(bool v, int line = __builtin_LINE()) { return wv_uniform64(v ? 1 : 0, line) != 0; }
 // a condition evaluated inside a section that ONE lane runs (no rendezvous: the other lanes are not there)
 ZSA_DEV bool wv_single_lane_b(bool v) { return v; }
+ZSA_DEV unsigned wv_single_lane_u32(unsigned v) { return v; }
 ZSA_DEV unsigned wv_bfe(unsigned x, unsigned off, unsigned w) { w &= 31; return w ? (x >> (off & 31)) & ((1u << w) - 1u) : 0; }
 ZSA_DEV unsigned wv_alignbyte(unsigned hi, unsigned lo, unsigned sh) { return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (8 * (sh & 3))); }
 ZSA_DEV unsigned wv_ldg8(const unsigned char* p) { return *p; }

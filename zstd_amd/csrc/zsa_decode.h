@@ -23,10 +23,16 @@
 #define ZSA_DEP_FENCE() wv_wave_fence()
 #endif
 
-// ---- packed sequence-table cell: baseValue | nextState<<32 | nbAdditionalBits<<48 | nbBits<<56
+// ---- packed sequence-table cell: baseValue | nbBits<<32 | nbAdditionalBits<<40 | nextState<<48.  The high word is what the
+// one-lane state walk works on: nbBits (<= 9) lies in its low five bits, which is where v_bfe_u32 reads a field's width and
+// offset from -- the word itself serves as that operand, no extraction.
 typedef u64 ZsaSeqCell;
 ZSA_DEV ZsaSeqCell zsa_seqcell(u32 base, u32 nextState, u32 addBits, u32 nbBits)
-{ return (u64)base | ((u64)nextState << 32) | ((u64)addBits << 48) | ((u64)nbBits << 56); }
+{ return (u64)base | ((u64)nbBits << 32) | ((u64)addBits << 40) | ((u64)nextState << 48); }
+ZSA_DEV u32 zsa_cell_base(ZsaSeqCell c) { return (u32)c; }
+ZSA_DEV u32 zsa_cell_nbBits(ZsaSeqCell c) { return (u32)(c >> 32) & 0x1Fu; }
+ZSA_DEV u32 zsa_cell_addBits(ZsaSeqCell c) { return (u32)(c >> 40) & 0xFFu; }
+ZSA_DEV u32 zsa_cell_next(ZsaSeqCell c) { return (u32)(c >> 48); }
 
 struct ZsaDDictDev {            // digested dictionary, device resident (zstd_ddict.c:37-45)
     const u8* content; u32 contentSize; u32 dictID; u32 entropyPresent;
@@ -870,34 +876,36 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                 u32 i = 0;
                 // (a sequence moves the cursor down by 12 bytes at most: `safe` sequences need no look at it)
                 while (wv_single_lane_b(i < n && pOff >= 16u)) {
-                u32 const safe = (pOff - 16u) / 12u + 1u, iEnd = (n - i) < safe ? n : i + safe;
+                u32 const safe = (pOff - 16u) / 12u + 1u, iEnd = wv_single_lane_u32((n - i) < safe ? n : i + safe);   // (a scalar: the loop counter stays one)
                 for (; i < iEnd; i++) {
                     ZsaSeqCell const ll = S->ll[stLL], ml = S->ml[stML], of = S->of[stOF];
                     u32 const llH = (u32)(ll >> 32), mlH = (u32)(ml >> 32), ofH = (u32)(of >> 32);
-                    // the three high words added as they are: byte 2 = extra bits of the sequence, byte 3 = state bits (the low
-                    // halves, three state bases below 512 each, cannot carry into them)
+                    // the three high words added as they are: byte 0 = state bits of the sequence (<= 27: no carry), byte 1 = its extra bits
                     u32 const sum = llH + mlH + ofH;
-                    u32 const E = (sum >> 16) & 0xFF, T = sum >> 24;
-                    u32 const llS = llH >> 24, mlS = mlH >> 24, ofS = ofH >> 24;
+                    u32 const E = (sum >> 8) & 0xFF, T = sum & 0xFF;
                     u64 const X0 = W << bc;
                     u32 const pk = stLL | (stML << 16);
                     u32 pk2 = stOF;
                     u32 sl, sm, so;
                     u32 const used = bc + E + T;
                     if (wv_single_lane_b(E + T <= 32)) {   // the usual case: all six fields lie in the top 32 bits of the window
+                        // (v_bfe_u32 takes a field's offset and width from the low five bits of its operands: the high words serve as
+                        // widths as they are, and the offsets need to be right modulo 32 only)
                         u32 const top = (u32)(X0 >> 32);
-                        u32 const at4 = 32u - E - llS, at5 = at4 - mlS, at6 = at5 - ofS;
+                        u32 const at4 = 0u - E - llH, at5 = at4 - mlH, at6 = at5 - ofH;
                         pOff -= used >> 3; bc = used & 7;
                         W = ((const Pk*)(S->bits + pOff))->v;
-                        sl = wv_bfe(top, at4, llS); sm = wv_bfe(top, at5, mlS); so = wv_bfe(top, at6, ofS);
+                        sl = wv_bfe(top, at4, llH); sm = wv_bfe(top, at5, mlH); so = wv_bfe(top, at6, ofH);
                     } else if (wv_single_lane_b(used <= 64)) {
+                        u32 const llS = llH & 31u, mlS = mlH & 31u, ofS = ofH & 31u;
                         u64 X = X0 << E;
                         pOff -= used >> 3; bc = used & 7;
                         W = ((const Pk*)(S->bits + pOff))->v;
                         ZSA_TAKE(sl, llS); ZSA_TAKE(sm, mlS); ZSA_TAKE(so, ofS);
                     } else {   // more than a window holds: refill after the offset and match-length bits (<= 7 + 31 + 16); the
                                // literal-length bits are then cut here and travel beside the record
-                        u32 const ofBits = (ofH >> 16) & 0xFF, mlBits = (mlH >> 16) & 0xFF, llBits = (llH >> 16) & 0xFF;
+                        u32 const ofBits = (ofH >> 8) & 0xFF, mlBits = (mlH >> 8) & 0xFF, llBits = (llH >> 8) & 0xFF;
+                        u32 const llS = llH & 31u, mlS = mlH & 31u, ofS = ofH & 31u;
                         u32 llx;
                         {   u32 const u1 = bc + ofBits + mlBits;
                             pOff -= u1 >> 3; bc = u1 & 7;
@@ -912,7 +920,7 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                         S->mStart[i] = llx; pk2 |= 0x80000000u;
                     }
                     S->seqLL[i] = (u32)X0; S->seqML[i] = (u32)(X0 >> 32); S->seqOF[i] = pk; S->outStart[i] = pk2;
-                    stLL = (llH & 0xFFFF) + sl; stML = (mlH & 0xFFFF) + sm; stOF = (ofH & 0xFFFF) + so;
+                    stLL = (llH >> 16) + sl; stML = (mlH >> 16) + sm; stOF = (ofH >> 16) + so;
                 }
                 }
                 k = i;
@@ -929,7 +937,7 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                     u32 const pk = S->seqOF[lane], pk2 = S->outStart[lane];
                     u64 X = ((u64)S->seqML[lane] << 32) | S->seqLL[lane];
                     ZsaSeqCell const ll = S->ll[pk & 0xFFFFu], ml = S->ml[pk >> 16], of = S->of[pk2 & 0xFFFFu];
-                    u32 const ofBits = (u32)(of >> 48) & 0xFF, mlBits = (u32)(ml >> 48) & 0xFF, llBits = (u32)(ll >> 48) & 0xFF;
+                    u32 const ofBits = zsa_cell_addBits(of), mlBits = zsa_cell_addBits(ml), llBits = zsa_cell_addBits(ll);
                     u32 ofx, mlx, llx;
                     ZSA_TAKE(ofx, ofBits); ZSA_TAKE(mlx, mlBits); ZSA_TAKE(llx, llBits);
                     if (pk2 >> 31) llx = S->mStart[lane];
@@ -987,7 +995,7 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                 for (u32 i = k; i < n; i++) {
                     ZsaSeqCell const ll = S->ll[stLL], ml = S->ml[stML], of = S->of[stOF];
                     u32 matchLength = (u32)ml, litLength = (u32)ll, offset;
-                    u32 const llBits = (u32)(ll >> 48) & 0xFF, mlBits = (u32)(ml >> 48) & 0xFF, ofBits = (u32)(of >> 48) & 0xFF;
+                    u32 const llBits = zsa_cell_addBits(ll), mlBits = zsa_cell_addBits(ml), ofBits = zsa_cell_addBits(of);
                     u32 const totalBits = (llBits + mlBits + ofBits) & 0xFF;
                     if (ofBits > 1) {
                         offset = (u32)of + zsa_br_readFast(b, ofBits);
@@ -1010,9 +1018,9 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                     if (mlBits > 0) matchLength += zsa_br_readFast(b, mlBits);
                     if (totalBits >= 57 - (ZSA_LLFSELog + ZSA_MLFSELog + ZSA_OffFSELog)) ZSA_RELOAD(b);
                     if (llBits > 0) litLength += zsa_br_readFast(b, llBits);
-                    stLL = (u32)((ll >> 32) & 0xFFFF) + zsa_br_read(b, (u32)(ll >> 56));
-                    stML = (u32)((ml >> 32) & 0xFFFF) + zsa_br_read(b, (u32)(ml >> 56));
-                    stOF = (u32)((of >> 32) & 0xFFFF) + zsa_br_read(b, (u32)(of >> 56));
+                    stLL = zsa_cell_next(ll) + zsa_br_read(b, zsa_cell_nbBits(ll));
+                    stML = zsa_cell_next(ml) + zsa_br_read(b, zsa_cell_nbBits(ml));
+                    stOF = zsa_cell_next(of) + zsa_br_read(b, zsa_cell_nbBits(of));
                     S->seqLL[i] = litLength; S->seqML[i] = matchLength; S->seqOF[i] = offset;
                     if (i + 1 < n || nbSeq > n) ZSA_RELOAD(b);
                 }

@@ -43,6 +43,8 @@ ZSA_DEV bool wv_uniform_b(bool v) { return wv_uniform(v ? 1u : 0u) != 0; }
 // code and every branch in it becomes exec-mask bookkeeping (save, xor, restore: five scalar instructions); with a single lane
 // in the mask the first active lane IS the lane, so its condition can be the condition of a scalar branch.
 ZSA_DEV bool wv_single_lane_b(bool v) { return __ballot(v) != 0; }   // (the compare writes the mask, the branch tests it: v_cmp, s_cmp_lg_u64, s_cbranch)
+// ... and a value computed there can be a scalar register (loop bounds: the counter then stays on the scalar unit)
+ZSA_DEV unsigned wv_single_lane_u32(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 // bytes [sh, sh+4) of the little-endian 8-byte value hi:lo, sh in 0..3
 // bits [off, off + w) of x (w == 0 gives 0; off is taken modulo 32)
 ZSA_DEV unsigned wv_bfe(unsigned x, unsigned off, unsigned w) { return __builtin_amdgcn_ubfe(x, off, w); }
