@@ -876,52 +876,52 @@ ZSA_DEV u32 zsa_decode_block(ZsaDecShared* S, ZsaDecCtx& C, const u8* src, u32 s
                 u32 i = 0;
                 // (a sequence moves the cursor down by 12 bytes at most: `safe` sequences need no look at it)
                 while (wv_single_lane_b(i < n && pOff >= 16u)) {
-                u32 const safe = (pOff - 16u) / 12u + 1u, iEnd = wv_single_lane_u32((n - i) < safe ? n : i + safe);   // (a scalar: the loop counter stays one)
-                for (; i < iEnd; i++) {
-                    ZsaSeqCell const ll = S->ll[stLL], ml = S->ml[stML], of = S->of[stOF];
-                    u32 const llH = (u32)(ll >> 32), mlH = (u32)(ml >> 32), ofH = (u32)(of >> 32);
-                    // the three high words added as they are: byte 0 = state bits of the sequence (<= 27: no carry), byte 1 = its extra bits
-                    u32 const sum = llH + mlH + ofH;
-                    u32 const E = (sum >> 8) & 0xFF, T = sum & 0xFF;
-                    u64 const X0 = W << bc;
-                    u32 const pk = stLL | (stML << 16);
-                    u32 pk2 = stOF;
-                    u32 sl, sm, so;
-                    u32 const used = bc + E + T;
-                    if (wv_single_lane_b(E + T <= 32)) {   // the usual case: all six fields lie in the top 32 bits of the window
-                        // (v_bfe_u32 takes a field's offset and width from the low five bits of its operands: the high words serve as
-                        // widths as they are, and the offsets need to be right modulo 32 only)
-                        u32 const top = (u32)(X0 >> 32);
-                        u32 const at4 = 0u - E - llH, at5 = at4 - mlH, at6 = at5 - ofH;
-                        pOff -= used >> 3; bc = used & 7;
-                        W = ((const Pk*)(S->bits + pOff))->v;
-                        sl = wv_bfe(top, at4, llH); sm = wv_bfe(top, at5, mlH); so = wv_bfe(top, at6, ofH);
-                    } else if (wv_single_lane_b(used <= 64)) {
-                        u32 const llS = llH & 31u, mlS = mlH & 31u, ofS = ofH & 31u;
-                        u64 X = X0 << E;
-                        pOff -= used >> 3; bc = used & 7;
-                        W = ((const Pk*)(S->bits + pOff))->v;
-                        ZSA_TAKE(sl, llS); ZSA_TAKE(sm, mlS); ZSA_TAKE(so, ofS);
-                    } else {   // more than a window holds: refill after the offset and match-length bits (<= 7 + 31 + 16); the
-                               // literal-length bits are then cut here and travel beside the record
-                        u32 const ofBits = (ofH >> 8) & 0xFF, mlBits = (mlH >> 8) & 0xFF, llBits = (llH >> 8) & 0xFF;
-                        u32 const llS = llH & 31u, mlS = mlH & 31u, ofS = ofH & 31u;
-                        u32 llx;
-                        {   u32 const u1 = bc + ofBits + mlBits;
-                            pOff -= u1 >> 3; bc = u1 & 7;
+                    u32 const safe = (pOff - 16u) / 12u + 1u, iEnd = wv_single_lane_u32((n - i) < safe ? n : i + safe);   // (a scalar: the loop counter stays one)
+                    for (; i < iEnd; i++) {
+                        ZsaSeqCell const ll = S->ll[stLL], ml = S->ml[stML], of = S->of[stOF];
+                        u32 const llH = (u32)(ll >> 32), mlH = (u32)(ml >> 32), ofH = (u32)(of >> 32);
+                        // the three high words added as they are: byte 0 = state bits of the sequence (<= 27: no carry), byte 1 = its extra bits
+                        u32 const sum = llH + mlH + ofH;
+                        u32 const E = (sum >> 8) & 0xFF, T = sum & 0xFF;
+                        u64 const X0 = W << bc;
+                        u32 const pk = stLL | (stML << 16);
+                        u32 pk2 = stOF;
+                        u32 sl, sm, so;
+                        u32 const used = bc + E + T;
+                        if (wv_single_lane_b(E + T <= 32)) {   // the usual case: all six fields lie in the top 32 bits of the window
+                            // (v_bfe_u32 takes a field's offset and width from the low five bits of its operands: the high words serve as
+                            // widths as they are, and the offsets need to be right modulo 32 only)
+                            u32 const top = (u32)(X0 >> 32);
+                            u32 const at4 = 0u - E - llH, at5 = at4 - mlH, at6 = at5 - ofH;
+                            pOff -= used >> 3; bc = used & 7;
                             W = ((const Pk*)(S->bits + pOff))->v;
-                        }
-                        u64 X = W << bc;
-                        ZSA_TAKE(llx, llBits); ZSA_TAKE(sl, llS); ZSA_TAKE(sm, mlS); ZSA_TAKE(so, ofS);
-                        {   u32 const u2 = bc + llBits + llS + mlS + ofS;
-                            pOff -= u2 >> 3; bc = u2 & 7;
+                            sl = wv_bfe(top, at4, llH); sm = wv_bfe(top, at5, mlH); so = wv_bfe(top, at6, ofH);
+                        } else if (wv_single_lane_b(used <= 64)) {
+                            u32 const llS = llH & 31u, mlS = mlH & 31u, ofS = ofH & 31u;
+                            u64 X = X0 << E;
+                            pOff -= used >> 3; bc = used & 7;
                             W = ((const Pk*)(S->bits + pOff))->v;
+                            ZSA_TAKE(sl, llS); ZSA_TAKE(sm, mlS); ZSA_TAKE(so, ofS);
+                        } else {   // more than a window holds: refill after the offset and match-length bits (<= 7 + 31 + 16); the
+                                   // literal-length bits are then cut here and travel beside the record
+                            u32 const ofBits = (ofH >> 8) & 0xFF, mlBits = (mlH >> 8) & 0xFF, llBits = (llH >> 8) & 0xFF;
+                            u32 const llS = llH & 31u, mlS = mlH & 31u, ofS = ofH & 31u;
+                            u32 llx;
+                            {   u32 const u1 = bc + ofBits + mlBits;
+                                pOff -= u1 >> 3; bc = u1 & 7;
+                                W = ((const Pk*)(S->bits + pOff))->v;
+                            }
+                            u64 X = W << bc;
+                            ZSA_TAKE(llx, llBits); ZSA_TAKE(sl, llS); ZSA_TAKE(sm, mlS); ZSA_TAKE(so, ofS);
+                            {   u32 const u2 = bc + llBits + llS + mlS + ofS;
+                                pOff -= u2 >> 3; bc = u2 & 7;
+                                W = ((const Pk*)(S->bits + pOff))->v;
+                            }
+                            S->mStart[i] = llx; pk2 |= 0x80000000u;
                         }
-                        S->mStart[i] = llx; pk2 |= 0x80000000u;
+                        S->seqLL[i] = (u32)X0; S->seqML[i] = (u32)(X0 >> 32); S->seqOF[i] = pk; S->outStart[i] = pk2;
+                        stLL = (llH >> 16) + sl; stML = (mlH >> 16) + sm; stOF = (ofH >> 16) + so;
                     }
-                    S->seqLL[i] = (u32)X0; S->seqML[i] = (u32)(X0 >> 32); S->seqOF[i] = pk; S->outStart[i] = pk2;
-                    stLL = (llH >> 16) + sl; stML = (mlH >> 16) + sm; stOF = (ofH >> 16) + so;
-                }
                 }
                 k = i;
                 b.ptr = stageLo + pOff; b.bitsConsumed = bc; b.container = W;
